@@ -1,0 +1,859 @@
+/* qk_oracle.c -- CPU restatement of Quisk's receive-DSP hot path.  TEST INFRASTRUCTURE ONLY.
+ * See qk_oracle.h for the pinning status of each group of functions.
+ *
+ * Build: gcc -O2 -ffp-contract=off (no FMA contraction: the reference is built by distutils with
+ * plain x86-64 flags, so every product and sum is rounded separately).
+ *
+ * The arithmetic (operand order, summation order, where a value is rounded) follows the cited
+ * reference lines exactly, because the filter kernels are checked bit for bit against the compiled
+ * reference.  The code organisation (index-based rings, explicit re/im parts, one receiver object
+ * instead of function statics) is this project's own.
+ */
+#include "qk_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define QK_COEF_TABLE(name, n) static const double name[n]
+#include "../quisk_amd/csrc/qk_coefs.inc"
+
+/* The 12 half-band constants: filter.c:359-362 (45-tap half band, taps 0 and 44 are zero). */
+static const double HB45[12] = {
+    0.000018566625444266, -0.000118469698701817, 0.000457318798253456, -0.001347840471412094,
+    0.003321838571445455, -0.007198422696929033, 0.014211106939802483, -0.026424776824073383,
+    0.048414810444971007, -0.096214669073304823, 0.314881034738348550, 0.500000000000000000 };
+
+const double *qko_table(const char *name, int *ntaps)
+{
+#define T(nm) if (!strcmp(name, #nm)) { *ntaps = (int)(sizeof(nm) / sizeof(double)); return nm; }
+    T(qk_h_dec2_98) T(qk_h_dec3_147) T(qk_h_dec5_245) T(qk_h_rs65_125) T(qk_h_sdriq53_55)
+    T(qk_h_sdriq111_114) T(qk_h_sdriq133_136) T(qk_h_sdriq167_174) T(qk_h_sdriq185_189)
+    T(qk_h_aud24p3_100) T(qk_h_aud24p4_50) T(qk_h_aud24p6_36) T(qk_h_fmhp_309) T(qk_h_dec16to8_62)
+#undef T
+    if (!strcmp(name, "hb45")) { *ntaps = 12; return HB45; }
+    *ntaps = 0;
+    return NULL;
+}
+
+/* ================================ filter.c kernels ================================== */
+
+void qko_cfir_init(qko_cfir *f, const double *h, int ntaps)
+{
+    memset(f, 0, sizeof *f);
+    f->h = h; f->ntaps = ntaps;
+    f->ring = (qko_cd *)calloc((size_t)ntaps, sizeof(qko_cd));
+}
+void qko_dfir_init(qko_dfir *f, const double *h, int ntaps)
+{
+    memset(f, 0, sizeof *f);
+    f->h = h; f->ntaps = ntaps;
+    f->ring = (double *)calloc((size_t)ntaps, sizeof(double));
+}
+void qko_cfir_free(qko_cfir *f) { free(f->ring); free(f->hc); free(f->scratch); memset(f, 0, sizeof *f); }
+void qko_dfir_free(qko_dfir *f) { free(f->ring); free(f->hc); free(f->scratch); memset(f, 0, sizeof *f); }
+
+void qko_filt_tune(qko_dfir *f, double freq, int ssb_upper)
+{   /* filter.c:35-58: c[i] = cexp(i 2 pi freq (i - D)) h[i]; lower sideband swaps re and im */
+    int i;
+    qko_cd coef, tune;
+    double D;
+    if (!f->hc) f->hc = (qko_cd *)malloc((size_t)f->ntaps * sizeof(qko_cd));
+    tune = I * 2.0 * M_PI * freq;
+    D = (f->ntaps - 1.0) / 2.0;
+    for (i = 0; i < f->ntaps; i++) {
+        coef = cexp(tune * (i - D)) * f->h[i];
+        f->hc[i] = ssb_upper ? coef : cimag(coef) + I * creal(coef);
+    }
+}
+
+/* y = sum_k h[k] ring[pos - k], accumulated from k = 0 upward (newest sample first) */
+static inline qko_cd cdot_real(const qko_cfir *f, const double *h, int first, int step, int terms)
+{
+    double ar = 0, ai = 0;
+    int j = f->pos, k;
+    const double *ph = h + first;
+    for (k = 0; k < terms; k++, ph += step) {
+        ar += creal(f->ring[j]) * *ph;
+        ai += cimag(f->ring[j]) * *ph;
+        if (--j < 0) j = f->ntaps - 1;
+    }
+    return ar + I * ai;
+}
+static inline double ddot_real(const qko_dfir *f, int first, int step, int terms)
+{
+    double a = 0;
+    int j = f->pos, k;
+    const double *ph = f->h + first;
+    for (k = 0; k < terms; k++, ph += step) {
+        a += f->ring[j] * *ph;
+        if (--j < 0) j = f->ntaps - 1;
+    }
+    return a;
+}
+#define RING_ADVANCE(f) do { if (++(f)->pos >= (f)->ntaps) (f)->pos = 0; } while (0)
+
+int qko_cdecimate(qko_cd *x, int n, qko_cfir *f, int decim)
+{
+    int i, nout = 0;
+    for (i = 0; i < n; i++) {
+        f->ring[f->pos] = x[i];
+        if (++f->decim_index >= decim) {
+            f->decim_index = 0;
+            x[nout++] = cdot_real(f, f->h, 0, 1, f->ntaps);
+        }
+        RING_ADVANCE(f);
+    }
+    return nout;
+}
+
+int qko_ccdecimate(qko_cd *x, int n, qko_cfir *f, int decim)
+{   /* complex coefficients from qko_filt_tune (cast the filter to qko_dfir for tuning, as the reference does) */
+    int i, k, j, nout = 0;
+    for (i = 0; i < n; i++) {
+        f->ring[f->pos] = x[i];
+        if (++f->decim_index >= decim) {
+            qko_cd acc = 0;
+            f->decim_index = 0;
+            j = f->pos;
+            for (k = 0; k < f->ntaps; k++) {
+                acc += f->ring[j] * f->hc[k];
+                if (--j < 0) j = f->ntaps - 1;
+            }
+            x[nout++] = acc;
+        }
+        RING_ADVANCE(f);
+    }
+    return nout;
+}
+
+int qko_ddecimate(double *x, int n, qko_dfir *f, int decim)
+{
+    int i, nout = 0;
+    for (i = 0; i < n; i++) {
+        f->ring[f->pos] = x[i];
+        if (++f->decim_index >= decim) {
+            f->decim_index = 0;
+            x[nout++] = ddot_real(f, 0, 1, f->ntaps);
+        }
+        RING_ADVANCE(f);
+    }
+    return nout;
+}
+
+int qko_dfilter(double *x, int n, qko_dfir *f)
+{
+    int i;
+    for (i = 0; i < n; i++) {
+        f->ring[f->pos] = x[i];
+        x[i] = ddot_real(f, 0, 1, f->ntaps);
+        RING_ADVANCE(f);
+    }
+    return n;
+}
+
+static qko_cd *c_scratch(qko_cd **buf, int *cap, const qko_cd *x, int n)
+{   /* the interpolators read their input from a private copy because the output overwrites x */
+    if (n > *cap) { free(*buf); *cap = n * 2; *buf = (qko_cd *)malloc((size_t)*cap * sizeof(qko_cd)); }
+    memcpy(*buf, x, (size_t)n * sizeof(qko_cd));
+    return *buf;
+}
+static double *d_scratch(double **buf, int *cap, const double *x, int n)
+{
+    if (n > *cap) { free(*buf); *cap = n * 2; *buf = (double *)malloc((size_t)*cap * sizeof(double)); }
+    memcpy(*buf, x, (size_t)n * sizeof(double));
+    return *buf;
+}
+
+int qko_cinterpolate(qko_cd *x, int n, qko_cfir *f, int interp)
+{
+    int i, j, nout = 0;
+    const qko_cd *in = c_scratch(&f->scratch, &f->nscratch, x, n);
+    for (i = 0; i < n; i++) {
+        f->ring[f->pos] = in[i];
+        for (j = 0; j < interp; j++) {
+            qko_cd y = cdot_real(f, f->h, j, interp, f->ntaps / interp);
+            if (nout < QKO_OUT_CAP) x[nout++] = y * interp;
+        }
+        RING_ADVANCE(f);
+    }
+    return nout;
+}
+
+int qko_dinterpolate(double *x, int n, qko_dfir *f, int interp)
+{
+    int i, j, nout = 0;
+    const double *in = d_scratch(&f->scratch, &f->nscratch, x, n);
+    for (i = 0; i < n; i++) {
+        f->ring[f->pos] = in[i];
+        for (j = 0; j < interp; j++) {
+            double y = ddot_real(f, j, interp, f->ntaps / interp);
+            if (nout < QKO_OUT_CAP) x[nout++] = y * interp;
+        }
+        RING_ADVANCE(f);
+    }
+    return nout;
+}
+
+int qko_cinterpdecim(qko_cd *x, int n, qko_cfir *f, int interp, int decim)
+{
+    int i, nout = 0;
+    const qko_cd *in = c_scratch(&f->scratch, &f->nscratch, x, n);
+    for (i = 0; i < n; i++) {
+        f->ring[f->pos] = in[i];
+        while (f->decim_index < interp) {
+            qko_cd y = cdot_real(f, f->h, f->decim_index, interp, f->ntaps / interp);
+            if (nout < QKO_OUT_CAP) x[nout++] = y * interp;
+            f->decim_index += decim;
+        }
+        RING_ADVANCE(f);
+        f->decim_index -= interp;
+    }
+    return nout;
+}
+
+int qko_cdecim2hb45(qko_cd *x, int n, qko_chb45 *f)
+{   /* even-numbered inputs feed the centre-tap delay line, odd-numbered inputs the symmetric part */
+    int i, k, nout = 0;
+    for (i = 0; i < n; i++) {
+        if (!f->toggle) {
+            f->toggle = 1;
+            memmove(f->center + 1, f->center, 10 * sizeof(qko_cd));
+            f->center[0] = x[i];
+        } else {
+            qko_cd acc;
+            f->toggle = 0;
+            memmove(f->samples + 1, f->samples, 21 * sizeof(qko_cd));
+            f->samples[0] = x[i];
+            acc = (f->samples[0] + f->samples[21]) * HB45[0];
+            for (k = 1; k < 11; k++)
+                acc = acc + (f->samples[k] + f->samples[21 - k]) * HB45[k];
+            x[nout++] = acc + f->center[10] * HB45[11];
+        }
+    }
+    return nout;
+}
+
+int qko_dinterp2hb45(double *x, int n, qko_dhb45 *f)
+{
+    int i, k, nout = 0;
+    const double *in = d_scratch(&f->scratch, &f->nscratch, x, n);
+    for (i = 0; i < n; i++) {
+        double acc = 0;
+        memmove(f->samples + 1, f->samples, 21 * sizeof(double));
+        f->samples[0] = in[i];
+        if (nout > QKO_OUT_CAP) continue;       /* sic: '>' (filter.c:421) */
+        x[nout++] = f->samples[11] * HB45[11] * 2;
+        for (k = 0; k < 11; k++)
+            acc += (f->samples[k] + f->samples[21 - k]) * HB45[k];
+        x[nout++] = acc * 2;
+    }
+    return nout;
+}
+
+int qko_cinterp2hb45(qko_cd *x, int n, qko_chb45 *f)
+{
+    int i, k, nout = 0;
+    const qko_cd *in = c_scratch(&f->scratch, &f->nscratch, x, n);
+    for (i = 0; i < n; i++) {
+        qko_cd acc = 0;
+        memmove(f->samples + 1, f->samples, 21 * sizeof(qko_cd));
+        f->samples[0] = in[i];
+        if (nout > QKO_OUT_CAP) continue;
+        x[nout++] = f->samples[11] * HB45[11] * 2;
+        for (k = 0; k < 11; k++)
+            acc += (f->samples[k] + f->samples[21 - k]) * HB45[k];
+        x[nout++] = acc * 2;
+    }
+    return nout;
+}
+
+/* ================================ quisk.c: planning ================================= */
+
+int qko_plan_decimation(int sample_rate, int *d2, int *d3, int *d5)
+{   /* quisk.c:1509-1547: exhaustive search with truncating integer division */
+    int best = sample_rate, b2 = 0, b3 = 0, b5 = 0, i2, i3, i5, i, r;
+    for (i2 = 0; i2 <= 6; i2++)
+        for (i3 = 0; i3 <= 3; i3++)
+            for (i5 = 0; i5 <= 3; i5++) {
+                r = sample_rate;
+                for (i = 0; i < i2; i++) r /= 2;
+                for (i = 0; i < i3; i++) r /= 3;
+                for (i = 0; i < i5; i++) r /= 5;
+                if (r >= 48000 && r < best) { b2 = i2; b3 = i3; b5 = i5; best = r; }
+            }
+    if (best >= 50000) best = best * 24 / 25;
+    if (d2) { *d2 = b2; *d3 = b3; *d5 = b5; }
+    return best;
+}
+
+static int rate_case(int sample_rate) { return (sample_rate + 100) / 1000; }
+
+int qko_decim_rate(int sample_rate)
+{   /* the value quisk_decim_srate holds when quisk_process_decimate returns (quisk.c:1607-1720) */
+    int d2, d3, d5, r, i;
+    switch (rate_case(sample_rate)) {
+    case 41: return 48000;
+    case 53: return sample_rate;
+    case 111: case 133: return sample_rate / 2;
+    case 185: return sample_rate / 3;
+    case 370: return sample_rate / 6;
+    case 740: return sample_rate / 12;
+    case 1333: return sample_rate / 24;
+    }
+    qko_plan_decimation(sample_rate, &d2, &d3, &d5);
+    r = sample_rate;
+    for (i = 0; i < d2; i++) r /= 2;     /* (d2-1) half-bands plus the final /2 */
+    for (i = 0; i < d3; i++) r /= 3;
+    for (i = 0; i < d5; i++) r /= 5;
+    if (r >= 50000) r = r * 24 / 25;
+    return r;
+}
+
+int qko_get_filter_rate(int sample_rate, int mode, int bandwidth)
+{   /* quisk.c:2661-2735, including the missing break after case 41 (falls into case 53) */
+    int decim;
+    switch (rate_case(sample_rate)) {
+    case 41:
+    case 53: decim = sample_rate; break;
+    case 111: case 133: decim = sample_rate / 2; break;
+    case 185: decim = sample_rate / 3; break;
+    case 370: decim = sample_rate / 6; break;
+    case 740: decim = sample_rate / 12; break;
+    case 1333: decim = sample_rate / 24; break;
+    default: decim = qko_plan_decimation(sample_rate, NULL, NULL, NULL); break;
+    }
+    switch (mode) {
+    case QKO_CWL: case QKO_CWU: return decim / 8;
+    case QKO_AM: return decim / 2;
+    case QKO_FM: case QKO_DGT_FM: case QKO_DGT_IQ: return decim;
+    case QKO_DGT_U: case QKO_DGT_L: return bandwidth < 3000 ? decim / 8 : decim;
+    case QKO_FDV_U: case QKO_FDV_L: return 8000;
+    default: return decim / 4;
+    }
+}
+
+/* ================================ quisk.c: AGC, fractional decimator ================ */
+
+void qko_agc_init(qko_agc *a, double max_out, int sample_rate)
+{
+    memset(a, 0, sizeof *a);
+    a->max_out = max_out; a->sample_rate = sample_rate;
+}
+void qko_agc_free(qko_agc *a) { free(a->ring); a->ring = NULL; }
+
+void qko_agc_process(qko_agc *a, qko_cd *x, int n, int is_cpx, int playback_rate,
+                     double release_gain, double release_time, int fm_mode)
+{
+    int i;
+    const double ceiling = a->max_out * QKO_CLIP32;
+    if (!a->buf_size) {     /* first call: set up and return the block untouched (quisk.c:2033-2050) */
+        if (a->sample_rate == 0) a->sample_rate = playback_rate;
+        a->buf_size = a->sample_rate * 15 / 1000;
+        a->index_read = a->index_start = a->is_clipping = 0;
+        a->themax = 1.0; a->gain = 100; a->delta = 0; a->target_gain = 100;
+        a->time_release = 1.0 - exp(-1.0 / a->sample_rate / release_time);
+        a->ring = (qko_cd *)calloc((size_t)a->buf_size, sizeof(qko_cd));
+        return;
+    }
+    for (i = 0; i < n; i++) {
+        qko_cd in = x[i];
+        double out_m, m;
+        x[i] = a->ring[a->index_read] * a->gain;
+        out_m = is_cpx ? cabs(x[i]) : fabs(creal(x[i]));
+        if (out_m > QKO_CLIP32) x[i] /= out_m;             /* sic: scales to unit magnitude (quisk.c:2065) */
+        a->ring[a->index_read] = in;
+        m = is_cpx ? cabs(in) : fabs(creal(in));
+        if (!a->is_clipping) {
+            if (m * a->gain > ceiling) {                    /* start a linear ramp down */
+                a->target_gain = ceiling / m;
+                a->delta = (a->gain - a->target_gain) / a->buf_size;
+                a->is_clipping = 1;
+                a->themax = m;
+                a->gain -= a->delta;
+            } else if (a->index_read == a->index_start) {   /* one buffer length measured: new release target */
+                double clip_gain = ceiling / a->themax;
+                if (fm_mode) a->target_gain = clip_gain;
+                else if (release_gain > clip_gain) a->target_gain = clip_gain;
+                else a->target_gain = release_gain;
+                a->themax = m;
+                a->gain = a->gain * (1.0 - a->time_release) + a->target_gain * a->time_release;
+            } else {
+                if (a->themax < m) a->themax = m;
+                a->gain = a->gain * (1.0 - a->time_release) + a->target_gain * a->time_release;
+            }
+        } else {
+            if (m > a->themax) {
+                double d;
+                a->themax = m;
+                a->target_gain = ceiling / m;
+                d = (a->gain - a->target_gain) / a->buf_size;
+                if (d > a->delta) a->delta = d;
+            }
+            a->gain -= a->delta;
+            if (a->gain <= a->target_gain) {
+                a->is_clipping = 0;
+                a->gain = a->target_gain;
+                a->themax = m;
+                a->index_start = a->index_read;
+            }
+        }
+        if (++a->index_read >= a->buf_size) a->index_read = 0;
+    }
+}
+
+void qko_fracdecim_init(qko_fracstate *s) { memset(s, 0, sizeof *s); s->dindex = 1; }
+
+int qko_fracdecim(qko_fracstate *s, qko_cd *x, int n, double fdecim)
+{   /* quisk.c:570-613: 4-point Lagrange interpolation at fractional position dindex */
+    int i, nout = 0;
+    for (i = 0; i < n; i++) {
+        s->c3 = x[i];
+        if (s->dindex < 2) {
+            double xm0 = s->dindex - 0, xm1 = s->dindex - 1, xm2 = s->dindex - 2, xm3 = s->dindex - 3;
+            x[nout++] = (xm1 * xm2 * xm3 * s->c0 / -6.0 + xm0 * xm2 * xm3 * s->c1 / 2.0 +
+                         xm0 * xm1 * xm3 * s->c2 / -2.0 + xm0 * xm1 * xm2 * s->c3 / 6.0);
+            s->dindex += fdecim - 1;
+        } else {
+            s->dindex -= 1;
+        }
+        s->c0 = s->c1; s->c1 = s->c2; s->c2 = s->c3;
+    }
+    return nout;
+}
+
+/* ================================ quisk.c: one receiver ============================= */
+
+struct qko_rx {
+    int sample_rate, playback_rate, mode, tune;
+    double release_gain, release_time;
+    qko_cd tune_vec;                                     /* rxTuneVector, quisk.c:2168 */
+    /* quisk_process_decimate Storage, quisk.c:1554-1574 */
+    int planned_rate, d2, d3, d5;
+    qko_chb45 hb[5];
+    qko_cfir sdriq111, sdriq53, sdriq133, sdriq167, sdriq185, dec3[3], dec5, dec5b, dec5s, dec2last, rs65;
+    int decim_srate, filter_srate;
+    /* quisk_process_demodulate Storage, quisk.c:1730-1747 */
+    qko_cd fm_1; double dc_remove, fm_a0, fm_a1, fm_b1, fm_x1, fm_y1;
+    qko_chb45 dem_hb4, dem_hb5; qko_dhb45 dem_hb6, dem_hb7;
+    qko_dfir aud24p3, aud24p4, aud12p2, aud24p6, fmhp;
+    qko_cfir dem_dec2;
+    /* receive band-pass: cFilterI/Q (quisk.c:94-96) and the two Storage rings (1124-1127, 1161-1165) */
+    double *fi, *fq; int nfilt, bandwidth;
+    int idx_c; double *ring_i, *ring_q;
+    int idx_d; qko_cd *ring_c;
+    qko_fracstate frac;
+    qko_chb45 play_hb[3];                                /* HalfBand7..9, quisk.c:2178-2180 */
+    qko_agc agc;                                         /* Agc1, quisk.c:2181 */
+    double *audio; int naudio;
+};
+
+qko_rx *qko_rx_new(int sample_rate, int playback_rate)
+{
+    int n, i;
+    const double *h;
+    qko_rx *rx = (qko_rx *)calloc(1, sizeof *rx);
+    rx->sample_rate = sample_rate; rx->playback_rate = playback_rate;
+    rx->mode = QKO_USB; rx->tune_vec = 1;
+    rx->release_gain = 80; rx->release_time = 1.0;       /* quisk.c:145-146 */
+#define CI(f, nm) do { h = qko_table(#nm, &n); qko_cfir_init(&rx->f, h, n); } while (0)
+#define DI(f, nm) do { h = qko_table(#nm, &n); qko_dfir_init(&rx->f, h, n); } while (0)
+    CI(sdriq111, qk_h_sdriq111_114); CI(sdriq53, qk_h_sdriq53_55); CI(sdriq133, qk_h_sdriq133_136);
+    CI(sdriq167, qk_h_sdriq167_174); CI(sdriq185, qk_h_sdriq185_189);
+    for (i = 0; i < 3; i++) CI(dec3[i], qk_h_dec3_147);
+    CI(dec5, qk_h_dec5_245); CI(dec5b, qk_h_dec5_245); CI(dec5s, qk_h_dec5_245);
+    CI(dec2last, qk_h_dec2_98); CI(rs65, qk_h_rs65_125);
+    DI(aud24p3, qk_h_aud24p3_100); DI(aud24p4, qk_h_aud24p4_50); DI(aud12p2, qk_h_aud24p4_50);
+    DI(aud24p6, qk_h_aud24p6_36); DI(fmhp, qk_h_fmhp_309);
+    CI(dem_dec2, qk_h_dec2_98);
+#undef CI
+#undef DI
+    rx->fm_1 = 10;                                       /* quisk.c:1763 */
+    {   /* de-emphasis coefficients, quisk.c:1764-1768 */
+        double www = tan(M_PI * 300.0 / 48000), nnn = 1.0 / (1.0 + www);
+        rx->fm_a0 = www * nnn; rx->fm_a1 = rx->fm_a0; rx->fm_b1 = nnn * (www - 1.0);
+    }
+    rx->fi = (double *)calloc(QKO_MAX_FILTER, sizeof(double));
+    rx->fq = (double *)calloc(QKO_MAX_FILTER, sizeof(double));
+    rx->ring_i = (double *)calloc(QKO_MAX_FILTER, sizeof(double));
+    rx->ring_q = (double *)calloc(QKO_MAX_FILTER, sizeof(double));
+    rx->ring_c = (qko_cd *)calloc(QKO_MAX_FILTER, sizeof(qko_cd));
+    qko_fracdecim_init(&rx->frac);
+    qko_agc_init(&rx->agc, 0.7, 0);
+    rx->decim_srate = qko_decim_rate(sample_rate);
+    rx->filter_srate = 48000;                            /* quisk.c:101 */
+    return rx;
+}
+
+void qko_rx_free(qko_rx *rx)
+{
+    int i;
+    if (!rx) return;
+    qko_cfir_free(&rx->sdriq111); qko_cfir_free(&rx->sdriq53); qko_cfir_free(&rx->sdriq133);
+    qko_cfir_free(&rx->sdriq167); qko_cfir_free(&rx->sdriq185);
+    for (i = 0; i < 3; i++) qko_cfir_free(&rx->dec3[i]);
+    qko_cfir_free(&rx->dec5); qko_cfir_free(&rx->dec5b); qko_cfir_free(&rx->dec5s);
+    qko_cfir_free(&rx->dec2last); qko_cfir_free(&rx->rs65); qko_cfir_free(&rx->dem_dec2);
+    qko_dfir_free(&rx->aud24p3); qko_dfir_free(&rx->aud24p4); qko_dfir_free(&rx->aud12p2);
+    qko_dfir_free(&rx->aud24p6); qko_dfir_free(&rx->fmhp);
+    for (i = 0; i < 5; i++) free(rx->hb[i].scratch);
+    free(rx->dem_hb4.scratch); free(rx->dem_hb5.scratch); free(rx->dem_hb6.scratch); free(rx->dem_hb7.scratch);
+    for (i = 0; i < 3; i++) free(rx->play_hb[i].scratch);
+    free(rx->fi); free(rx->fq); free(rx->ring_i); free(rx->ring_q); free(rx->ring_c);
+    qko_agc_free(&rx->agc);
+    free(rx->audio);
+    free(rx);
+}
+
+void qko_rx_set_tune(qko_rx *rx, int tune_hz) { rx->tune = tune_hz; }
+void qko_rx_set_mode(qko_rx *rx, int mode) { rx->mode = mode; }
+void qko_rx_set_agc(qko_rx *rx, double release_gain, double release_time)
+{ rx->release_gain = release_gain; rx->release_time = release_time; }
+int qko_rx_decim_srate(const qko_rx *rx) { return rx->decim_srate; }
+int qko_rx_filter_srate(const qko_rx *rx) { return rx->filter_srate; }
+
+int qko_rx_set_filter(qko_rx *rx, const double *fi, const double *fq, int n, int bandwidth)
+{
+    if (n >= QKO_MAX_FILTER || n < 0) return -1;         /* quisk.c:4216 */
+    memcpy(rx->fi, fi, (size_t)n * sizeof(double));
+    memcpy(rx->fq, fq, (size_t)n * sizeof(double));
+    rx->nfilt = n; rx->bandwidth = bandwidth;
+    return 0;
+}
+
+void qko_rx_mix(qko_rx *rx, qko_cd *x, int n)
+{   /* quisk.c:2350-2361; the vector is neither renormalised nor reset on a frequency change */
+    int i;
+    double tune = rx->tune;
+    qko_cd phase;
+    if (tune == 0) return;
+    phase = cexp((I * -2.0 * M_PI * tune) / rx->sample_rate);
+    for (i = 0; i < n; i++) {
+        x[i] *= rx->tune_vec;
+        rx->tune_vec *= phase;
+    }
+}
+
+int qko_rx_decimate(qko_rx *rx, qko_cd *x, int n)
+{   /* quisk.c:1600-1721 */
+    int i2, i3, i5, rate = rx->sample_rate;
+    if (rx->planned_rate != rate) {
+        rx->planned_rate = rate;
+        qko_plan_decimation(rate, &rx->d2, &rx->d3, &rx->d5);
+    }
+    switch (rate_case(rate)) {
+    case 41: rx->decim_srate = 48000; return n;
+    case 53: rx->decim_srate = rate; return qko_cdecimate(x, n, &rx->sdriq53, 1);
+    case 111: rx->decim_srate = rate / 2; return qko_cdecimate(x, n, &rx->sdriq111, 2);
+    case 133: rx->decim_srate = rate / 2; return qko_cdecimate(x, n, &rx->sdriq133, 2);
+    case 185: rx->decim_srate = rate / 3; return qko_cdecimate(x, n, &rx->sdriq185, 3);
+    case 370:
+        rx->decim_srate = rate / 6;
+        n = qko_cdecim2hb45(x, n, &rx->hb[1]);
+        return qko_cdecimate(x, n, &rx->sdriq185, 3);
+    case 740:
+        rx->decim_srate = rate / 12;
+        n = qko_cdecim2hb45(x, n, &rx->hb[1]);
+        n = qko_cdecim2hb45(x, n, &rx->hb[2]);
+        return qko_cdecimate(x, n, &rx->sdriq185, 3);
+    case 1333:
+        rx->decim_srate = rate / 24;
+        n = qko_cdecim2hb45(x, n, &rx->hb[0]);
+        n = qko_cdecim2hb45(x, n, &rx->hb[1]);
+        n = qko_cdecim2hb45(x, n, &rx->hb[2]);
+        return qko_cdecimate(x, n, &rx->sdriq167, 3);
+    }
+    rx->decim_srate = rate;
+    for (i2 = 0; i2 < rx->d2 - 1 && i2 < 5; i2++) {      /* all but the last /2 are half-bands */
+        n = qko_cdecim2hb45(x, n, &rx->hb[i2]);
+        rx->decim_srate /= 2;
+    }
+    for (i3 = 0; i3 < rx->d3; i3++) {
+        n = qko_cdecimate(x, n, &rx->dec3[i3], 3);
+        rx->decim_srate /= 3;
+    }
+    for (i5 = 0; i5 < rx->d5; i5++) {
+        n = qko_cdecimate(x, n, i5 == 0 ? &rx->dec5 : i5 == 1 ? &rx->dec5b : &rx->dec5s, 5);
+        rx->decim_srate /= 5;
+    }
+    if (rx->d2 > 0) {
+        n = qko_cdecimate(x, n, &rx->dec2last, 2);
+        rx->decim_srate /= 2;
+    }
+    if (rx->decim_srate >= 50000) {                      /* 24/25 resampler; the second stage shares dec5s (quisk.c:1713) */
+        rx->decim_srate = rx->decim_srate * 24 / 25;
+        n = qko_cinterpdecim(x, n, &rx->rs65, 6, 5);
+        n = qko_cinterpdecim(x, n, &rx->dec5s, 4, 5);
+    }
+    return n;
+}
+
+static qko_cd rx_bandpass_iq(qko_rx *rx, qko_cd s)
+{   /* cRxFilterOut, quisk.c:1154-1192: I taps on the real part, Q taps on the imaginary part;
+     * the newest sample meets tap 0 and the index then runs forward through the ring */
+    double ai = 0, aq = 0;
+    int j, k, N = rx->nfilt;
+    if (!N) return s;
+    if (rx->idx_c >= N) rx->idx_c = 0;
+    rx->ring_i[rx->idx_c] = creal(s);
+    rx->ring_q[rx->idx_c] = cimag(s);
+    j = rx->idx_c;
+    for (k = 0; k < N; k++) {
+        ai += rx->ring_i[j] * rx->fi[k];
+        aq += rx->ring_q[j] * rx->fq[k];
+        if (++j >= N) j = 0;
+    }
+    rx->idx_c++;
+    return ai + I * aq;
+}
+
+static qko_cd rx_bandpass_real(qko_rx *rx, qko_cd s)
+{   /* dRxFilterOut, quisk.c:1118-1152: I taps on the complex sample */
+    double ar = 0, ai = 0;
+    int j, k, N = rx->nfilt;
+    if (!N) return s;
+    if (rx->idx_d >= N) rx->idx_d = 0;
+    rx->ring_c[rx->idx_d] = s;
+    j = rx->idx_d;
+    for (k = 0; k < N; k++) {
+        ar += creal(rx->ring_c[j]) * rx->fi[k];
+        ai += cimag(rx->ring_c[j]) * rx->fi[k];
+        if (++j >= N) j = 0;
+    }
+    rx->idx_d++;
+    return ar + I * ai;
+}
+
+int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
+{   /* quisk.c:1778-2014 for the modes that need no codec: CW, SSB, AM, FM, DGT-U/L/IQ/FM.
+     * Off-by-default side branches (auto-notch, SSB squelch, audio measurement) are left out. */
+    int i, narrow;
+    qko_cd c, p;
+    double m, d, di;
+    switch (rx->mode) {
+    case QKO_CWL: case QKO_CWU:
+        rx->filter_srate = rx->decim_srate / 8;
+        n = qko_cdecim2hb45(x, n, &rx->dem_hb5);
+        n = qko_cdecim2hb45(x, n, &rx->dem_hb4);
+        n = qko_cdecimate(x, n, &rx->dem_dec2, 2);
+        for (i = 0; i < n; i++) {
+            c = rx_bandpass_iq(rx, x[i]);
+            a[i] = rx->mode == QKO_CWL ? creal(c) + cimag(c) : creal(c) - cimag(c);
+        }
+        n = qko_dinterpolate(a, n, &rx->aud12p2, 2);
+        n = qko_dinterp2hb45(a, n, &rx->dem_hb6);
+        n = qko_dinterp2hb45(a, n, &rx->dem_hb7);
+        break;
+    case QKO_AM:
+        rx->filter_srate = rx->decim_srate / 2;
+        n = qko_cdecimate(x, n, &rx->dem_dec2, 2);
+        for (i = 0; i < n; i++) {
+            c = rx_bandpass_real(rx, x[i]);
+            m = cabs(c);
+            d = m + rx->dc_remove * 0.99;                /* DC removal, quisk.c:1869-1871 */
+            a[i] = d - rx->dc_remove;
+            rx->dc_remove = d;
+        }
+        n = qko_dfilter(a, n, &rx->aud24p6);
+        n = qko_dinterp2hb45(a, n, &rx->dem_hb7);
+        break;
+    case QKO_FM: case QKO_DGT_FM:
+        rx->filter_srate = rx->decim_srate;
+        for (i = 0; i < n; i++) {
+            c = rx_bandpass_real(rx, x[i]);
+            p = c * conj(rx->fm_1);
+            rx->fm_1 = c;
+            di = rx->filter_srate * carg(p);
+            a[i] = rx->fm_y1 = di * rx->fm_a0 + rx->fm_x1 * rx->fm_a1 - rx->fm_y1 * rx->fm_b1;
+            rx->fm_x1 = di;
+        }
+        n = qko_ddecimate(a, n, &rx->aud24p3, 2);
+        n = qko_dfilter(a, n, &rx->fmhp);
+        n = qko_dinterp2hb45(a, n, &rx->dem_hb6);
+        break;
+    case QKO_DGT_U: case QKO_DGT_L:
+        narrow = rx->bandwidth < 3000;                   /* DGT_NARROW_FREQ, quisk.c:35 */
+        if (narrow) {
+            rx->filter_srate = rx->decim_srate / 8;
+            n = qko_cdecim2hb45(x, n, &rx->dem_hb5);
+            n = qko_cdecim2hb45(x, n, &rx->dem_hb4);
+            n = qko_cdecimate(x, n, &rx->dem_dec2, 2);
+        } else {
+            rx->filter_srate = rx->decim_srate;
+        }
+        for (i = 0; i < n; i++) {
+            c = rx_bandpass_iq(rx, x[i]);
+            a[i] = rx->mode == QKO_DGT_L ? creal(c) + cimag(c) : creal(c) - cimag(c);
+        }
+        if (narrow) {
+            n = qko_dinterpolate(a, n, &rx->aud12p2, 2);
+            n = qko_dinterp2hb45(a, n, &rx->dem_hb6);
+            n = qko_dinterp2hb45(a, n, &rx->dem_hb7);
+        }
+        break;
+    case QKO_DGT_IQ:
+        rx->filter_srate = rx->decim_srate;
+        if (rx->bandwidth < 19000)
+            for (i = 0; i < n; i++) x[i] = rx_bandpass_real(rx, x[i]);
+        break;
+    default:        /* LSB, USB and every mode the reference's switch sends to its default label */
+        rx->filter_srate = rx->decim_srate / 4;
+        n = qko_cdecim2hb45(x, n, &rx->dem_hb5);
+        n = qko_cdecimate(x, n, &rx->dem_dec2, 2);
+        for (i = 0; i < n; i++) {
+            c = rx_bandpass_iq(rx, x[i]);
+            a[i] = rx->mode == QKO_LSB ? creal(c) + cimag(c) : creal(c) - cimag(c);
+        }
+        n = qko_dinterpolate(a, n, &rx->aud24p4, 2);
+        n = qko_dinterp2hb45(a, n, &rx->dem_hb7);
+        break;
+    }
+    return n;
+}
+
+int qko_rx_process(qko_rx *rx, qko_cd *x, int n)
+{
+    int i;
+    if (n <= 0) return n;
+    if (n * 2 > rx->naudio) {                            /* quisk.c:2198-2212 */
+        free(rx->audio);
+        rx->naudio = n * 2;
+        rx->audio = (double *)malloc((size_t)rx->naudio * sizeof(double));
+    }
+    qko_rx_mix(rx, x, n);
+    n = qko_rx_decimate(rx, x, n);
+    n = qko_rx_demodulate(rx, x, rx->audio, n);
+    if (rx->mode != QKO_DGT_IQ)                          /* mono on both channels, quisk.c:2495-2501 */
+        for (i = 0; i < n; i++) x[i] = rx->audio[i] + I * rx->audio[i];
+    if (rx->decim_srate != 48000) {                      /* quisk.c:2528-2532 */
+        n = qko_fracdecim(&rx->frac, x, n, rx->decim_srate / 48000.0);
+        rx->decim_srate = 48000;
+    }
+    switch (rx->playback_rate / 48000) {                 /* quisk.c:2535-2553 */
+    case 8: n = qko_cinterp2hb45(x, n, &rx->play_hb[0]); n = qko_cinterp2hb45(x, n, &rx->play_hb[1]);
+            n = qko_cinterp2hb45(x, n, &rx->play_hb[2]); break;
+    case 4: n = qko_cinterp2hb45(x, n, &rx->play_hb[0]); n = qko_cinterp2hb45(x, n, &rx->play_hb[1]); break;
+    case 2: n = qko_cinterp2hb45(x, n, &rx->play_hb[0]); break;
+    default: break;
+    }
+    qko_agc_process(&rx->agc, x, n, rx->mode == QKO_DGT_IQ, rx->playback_rate, rx->release_gain,
+                    rx->release_time, rx->mode == QKO_FM || rx->mode == QKO_DGT_FM);
+    return n;
+}
+
+void qko_rx_process_many(qko_rx **rx, int nrx, const qko_cd *x, int n, qko_cd *out, long out_stride, int *counts)
+{
+    int r;
+    qko_cd *work = (qko_cd *)malloc((size_t)(n > 0 ? n : 1) * sizeof(qko_cd));
+    for (r = 0; r < nrx; r++) {
+        int m;
+        memcpy(work, x, (size_t)n * sizeof(qko_cd));
+        m = qko_rx_process(rx[r], work, n);
+        memcpy(out + r * out_stride, work, (size_t)(m > 0 ? m : 0) * sizeof(qko_cd));
+        counts[r] = m;
+    }
+    free(work);
+}
+
+/* ================================ quisk.c: display spectrum ========================= */
+
+void qko_fft(qko_cd *x, int n)
+{   /* plain radix-2 decimation in time; twiddles from cexp per index, so the error stays ~1e-16 log2 n */
+    int i, j, len, k, bits = 0;
+    qko_cd *w;
+    while ((1 << bits) < n) bits++;
+    for (i = 0; i < n; i++) {
+        unsigned r = 0, v = (unsigned)i;
+        for (k = 0; k < bits; k++) { r = (r << 1) | (v & 1); v >>= 1; }
+        if ((int)r > i) { qko_cd t = x[i]; x[i] = x[r]; x[r] = t; }
+    }
+    w = (qko_cd *)malloc((size_t)(n / 2 > 0 ? n / 2 : 1) * sizeof(qko_cd));
+    for (i = 0; i < n / 2; i++) w[i] = cexp(-2.0 * M_PI * I * (double)i / (double)n);
+    for (len = 2; len <= n; len <<= 1) {
+        int half = len / 2, stride = n / len;
+        for (i = 0; i < n; i += len)
+            for (j = 0; j < half; j++) {
+                qko_cd u = x[i + j], t;
+                qko_cd b = x[i + j + half], tw = w[j * stride];
+                t = (creal(b) * creal(tw) - cimag(b) * cimag(tw)) + I * (creal(b) * cimag(tw) + cimag(b) * creal(tw));
+                x[i + j] = u + t;
+                x[i + j + half] = u - t;
+            }
+    }
+    free(w);
+}
+
+void qko_hann_window(double *w, int n)
+{
+    int i, j;
+    for (i = 0, j = -n / 2; i < n; i++, j++) w[i] = 0.5 + 0.5 * cos(2. * M_PI * j / n);
+}
+
+void qko_graph_init(qko_graph *g, int fft_size, int data_width, int sample_rate)
+{
+    memset(g, 0, sizeof *g);
+    g->fft_size = fft_size; g->data_width = data_width; g->sample_rate = sample_rate;
+    g->window = (double *)malloc((size_t)fft_size * sizeof(double));
+    g->avg = (double *)calloc((size_t)fft_size, sizeof(double));
+    qko_hann_window(g->window, fft_size);
+}
+void qko_graph_free(qko_graph *g) { free(g->window); free(g->avg); memset(g, 0, sizeof *g); }
+void qko_graph_set_passband(qko_graph *g, int rx_tune, int filter_start_offset, int filter_bandwidth)
+{ g->rx_tune = rx_tune; g->filter_start_offset = filter_start_offset; g->filter_bandwidth = filter_bandwidth; }
+
+void qko_graph_add_frame(qko_graph *g, qko_cd *s)
+{
+    int i, j, k, n, N = g->fft_size;
+    double d2;
+    qko_cd c;
+    for (i = 0; i < N; i++) s[i] *= g->window[i];
+    qko_fft(s, N);
+    /* S-meter: power over the receive pass band, quisk.c:4659-4680 */
+    d2 = (double)g->filter_bandwidth * N / g->sample_rate;
+    i = (int)((double)(g->rx_tune + g->filter_start_offset) * N / g->sample_rate + 0.5);
+    n = (int)(floor(d2) + 0.01);
+    if (i > -N / 2 && i + n + 1 < N / 2) {
+        for (j = 0; j < n; i++, j++) {
+            c = i < 0 ? s[N + i] : s[i];
+            g->meter = g->meter + (creal(c) * creal(c) + cimag(c) * cimag(c));
+        }
+        c = i < 0 ? s[N + i] : s[i];
+        g->meter = g->meter + (creal(c) * creal(c) + cimag(c) * cimag(c)) * (d2 - n);
+    }
+    /* magnitude average, negative frequencies first, quisk.c:4703-4710 */
+    g->count++;
+    k = 0;
+    for (i = N / 2; i < N; i++) g->avg[k++] += cabs(s[i]);
+    for (i = 0; i < N / 2; i++) g->avg[k++] += cabs(s[i]);
+}
+
+int qko_graph_release(qko_graph *g, double zoom, double deltaf, double *out, double *smeter)
+{
+    int i, j, k, n, N = g->fft_size, W = g->data_width, count = g->count;
+    double d2, scale, sm;
+    if (count <= 0) return 0;
+    n = (int)(zoom * (double)N / W + 0.5);
+    if (n < 1) n = 1;
+    for (i = 0; i < W; i++) {                            /* in place, like the reference (can alias for zoom < 1) */
+        k = (int)(N * (deltaf / g->sample_rate + zoom * ((double)i / W - 0.5) + 0.5) + 0.1);
+        d2 = 0.0;
+        for (j = 0; j < n; j++, k++)
+            if (k >= 0 && k < N) d2 += g->avg[k];
+        g->avg[i] = d2;
+    }
+    scale = 1.0 / 2147483647.0 / N;
+    sm = g->meter * scale * scale / count;
+    g->meter = 0;
+    sm = sm > 0 ? 10.0 * log10(sm) : -160.0;
+    sm += 4.25969;
+    if (smeter) *smeter = sm;
+    scale = log10(count) + log10(N) + 31.0 * log10(2.0);
+    scale *= 20.0;
+    for (i = 0; i < W; i++) {
+        d2 = 20.0 * log10(g->avg[i]) - scale;
+        if (d2 < -200) d2 = -200;
+        out[i] = d2;
+    }
+    for (i = 0; i < N; i++) g->avg[i] = 0;
+    g->count = 0;
+    return count;
+}

@@ -1,0 +1,135 @@
+/* qk_oracle.h -- CPU restatement of Quisk's receive-DSP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under quisk_amd/ may include, link or load
+ * this; it is the checker the HIP path is compared with (tests/, smoke(), and the
+ * cpu_baseline leg of bench.py).
+ *
+ * Pinning status:
+ *   - filter kernels (qko_cdecimate ... qko_cinterp2hb45, qko_filt_tune): PINNED,
+ *     bit-exact against the reference's own filter.c compiled unmodified into
+ *     oracle/_ref/libquisk_filter_ref.so (tests/test_oracle_vs_ref.py) and against
+ *     tests/golden/filter_kernels.npz generated from it.
+ *   - everything restated from quisk.c (mixer, PlanDecimation, cRxFilterOut,
+ *     dRxFilterOut, demodulators, cFracDecim, process_agc, graph post-processing):
+ *     PARITY UNPINNED.  quisk.c needs <fftw3.h>, which this image lacks, so it is
+ *     unbuildable here, and the reference ships no tests or golden vectors.  These
+ *     functions follow the cited lines of quisk.c by reading.
+ *   - FFT: the reference calls FFTW3 (not vendored, version unpinned).  qko_fft is
+ *     the mathematical DFT in double, checked against numpy.fft in tests.
+ */
+#ifndef QK_ORACLE_H
+#define QK_ORACLE_H
+#include <complex.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef double complex qko_cd;
+
+/* rx_mode_type, quisk.h:48-63 */
+enum { QKO_CWL = 0, QKO_CWU = 1, QKO_LSB = 2, QKO_USB = 3, QKO_AM = 4, QKO_FM = 5, QKO_EXT = 6,
+       QKO_DGT_U = 7, QKO_DGT_L = 8, QKO_DGT_IQ = 9, QKO_IMD = 10, QKO_FDV_U = 11, QKO_FDV_L = 12,
+       QKO_DGT_FM = 13 };
+
+#define QKO_CLIP32 2147483647.0          /* quisk.h:13 */
+#define QKO_OUT_CAP (66000 * 8 / 10)     /* SAMP_BUFFER_SIZE*8/10, filter.c:135 */
+#define QKO_MAX_FILTER 10001             /* quisk.h:10 */
+
+/* ---- filter.c kernels ------------------------------------------------------------ */
+typedef struct {            /* struct quisk_cFilter, filter.h:1-10 */
+    const double *h; qko_cd *hc; int ntaps; int decim_index; qko_cd *ring; int pos;
+    qko_cd *scratch; int nscratch;
+} qko_cfir;
+typedef struct {            /* struct quisk_dFilter, filter.h:12-21 */
+    const double *h; qko_cd *hc; int ntaps; int decim_index; double *ring; int pos;
+    double *scratch; int nscratch;
+} qko_dfir;
+typedef struct { int toggle; qko_cd samples[22]; qko_cd center[11]; qko_cd *scratch; int nscratch; } qko_chb45; /* filter.h:23-29 */
+typedef struct { int toggle; double samples[22]; double center[11]; double *scratch; int nscratch; } qko_dhb45; /* filter.h:31-37 */
+
+void qko_cfir_init(qko_cfir *f, const double *h, int ntaps);           /* filter.c:9-20 */
+void qko_dfir_init(qko_dfir *f, const double *h, int ntaps);           /* filter.c:22-33 */
+void qko_cfir_free(qko_cfir *f);
+void qko_dfir_free(qko_dfir *f);
+void qko_filt_tune(qko_dfir *f, double freq, int ssb_upper);           /* filter.c:35-58 */
+int qko_cdecimate(qko_cd *x, int n, qko_cfir *f, int decim);           /* filter.c:180-206 */
+int qko_ccdecimate(qko_cd *x, int n, qko_cfir *f, int decim);          /* filter.c:208-234 */
+int qko_ddecimate(double *x, int n, qko_dfir *f, int decim);           /* filter.c:236-262 */
+int qko_dfilter(double *x, int n, qko_dfir *f);                        /* filter.c:324-347 */
+int qko_cinterpolate(qko_cd *x, int n, qko_cfir *f, int interp);       /* filter.c:108-142 */
+int qko_dinterpolate(double *x, int n, qko_dfir *f, int interp);       /* filter.c:144-178 */
+int qko_cinterpdecim(qko_cd *x, int n, qko_cfir *f, int interp, int decim); /* filter.c:264-301 */
+int qko_cdecim2hb45(qko_cd *x, int n, qko_chb45 *f);                   /* filter.c:354-394 */
+int qko_dinterp2hb45(double *x, int n, qko_dhb45 *f);                  /* filter.c:397-430 */
+int qko_cinterp2hb45(qko_cd *x, int n, qko_chb45 *f);                  /* filter.c:432-465 */
+
+/* ---- quisk.c: planning ----------------------------------------------------------- */
+int qko_plan_decimation(int sample_rate, int *d2, int *d3, int *d5);   /* quisk.c:1509-1547 */
+int qko_decim_rate(int sample_rate);      /* quisk_decim_srate after quisk_process_decimate, quisk.c:1607-1720 */
+int qko_get_filter_rate(int sample_rate, int mode, int bandwidth);     /* quisk.c:2661-2735 */
+
+/* ---- quisk.c: one receiver ("bank") ---------------------------------------------- */
+typedef struct {            /* struct AgcState, quisk.c:51-64 */
+    double max_out; int sample_rate; int buf_size; int index_read, index_start, is_clipping;
+    double themax, gain, delta, target_gain, time_release; qko_cd *ring;
+} qko_agc;
+
+typedef struct qko_rx qko_rx;
+
+/* A receiver owns every piece of state quisk_process_samples keeps for bank 0 (function statics
+ * at quisk.c:2161-2181, Storage[] at 1554-1574 and 1730-1747, cRxFilterOut/dRxFilterOut rings). */
+qko_rx *qko_rx_new(int sample_rate, int playback_rate);
+void qko_rx_free(qko_rx *rx);
+void qko_rx_set_tune(qko_rx *rx, int tune_hz);                         /* set_tune, quisk.c:4323 */
+void qko_rx_set_mode(qko_rx *rx, int mode);                            /* set_rx_mode, quisk.c:4262 */
+int  qko_rx_set_filter(qko_rx *rx, const double *fi, const double *fq, int n, int bandwidth); /* set_filters, quisk.c:4192 */
+void qko_rx_set_agc(qko_rx *rx, double release_gain, double release_time); /* set_agc 4184; agc_release_time 146 */
+/* quisk_process_samples (quisk.c:2149-2616), key up, default options: in place, returns the number
+ * of stereo output samples written to the head of x.  n <= 66000 like the reference's buffer. */
+int  qko_rx_process(qko_rx *rx, qko_cd *x, int n);
+/* stages, exposed for per-stage parity tests */
+void qko_rx_mix(qko_rx *rx, qko_cd *x, int n);                         /* quisk.c:2350-2361 */
+int  qko_rx_decimate(qko_rx *rx, qko_cd *x, int n);                    /* quisk.c:1549-1722 */
+int  qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *audio, int n);   /* quisk.c:1724-2020 */
+int  qko_rx_decim_srate(const qko_rx *rx);
+int  qko_rx_filter_srate(const qko_rx *rx);
+
+void qko_agc_init(qko_agc *a, double max_out, int sample_rate);
+void qko_agc_free(qko_agc *a);
+/* process_agc, quisk.c:2022-2147.  playback_rate is used when a->sample_rate is 0;
+ * fm_mode is (rxMode == FM || rxMode == DGT_FM), quisk.c:2088. */
+void qko_agc_process(qko_agc *a, qko_cd *x, int n, int is_cpx, int playback_rate,
+                     double release_gain, double release_time, int fm_mode);
+
+typedef struct { double dindex; qko_cd c0, c1, c2, c3; } qko_fracstate; /* statics at quisk.c:575-576 */
+void qko_fracdecim_init(qko_fracstate *s);
+int  qko_fracdecim(qko_fracstate *s, qko_cd *x, int n, double fdecim);  /* quisk.c:570-613 */
+
+/* ---- quisk.c: display spectrum --------------------------------------------------- */
+void qko_fft(qko_cd *x, int n);               /* forward complex DFT in place, n a power of two */
+void qko_hann_window(double *w, int n);       /* quisk.c:5091-5096 */
+typedef struct {
+    int fft_size, data_width, sample_rate; double *window; double *avg; int count; double meter;
+    int rx_tune, filter_start_offset, filter_bandwidth;
+} qko_graph;
+void qko_graph_init(qko_graph *g, int fft_size, int data_width, int sample_rate);
+void qko_graph_free(qko_graph *g);
+void qko_graph_set_passband(qko_graph *g, int rx_tune, int filter_start_offset, int filter_bandwidth);
+/* one filled FFT buffer: window, FFT, S-meter sum, magnitude average (quisk.c:4651-4710).  frame is overwritten. */
+void qko_graph_add_frame(qko_graph *g, qko_cd *frame);
+/* release (quisk.c:4713-4753): pixel binning, dB scaling; returns the averaged-frame count, resets the average.
+ * out has data_width doubles; *smeter receives the S-meter value (quisk.c:4728-4737). */
+int qko_graph_release(qko_graph *g, double zoom, double deltaf, double *out, double *smeter);
+
+/* ---- batch driver used as the timed CPU baseline --------------------------------- */
+/* run nrx receivers (already configured) over the same input block; audio of receiver r is written to
+ * out + r*out_stride; counts[r] receives the sample count.  Receivers are processed one after the other. */
+void qko_rx_process_many(qko_rx **rx, int nrx, const qko_cd *x, int n, qko_cd *out, long out_stride, int *counts);
+
+const double *qko_table(const char *name, int *ntaps);   /* coefficient tables by project name */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

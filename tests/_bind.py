@@ -1,0 +1,222 @@
+"""ctypes bindings for the checker libraries (test infrastructure).
+
+  ORACLE : oracle/libqk_oracle.so              this project's CPU restatement
+  REF    : oracle/_ref/libquisk_filter_ref.so  the reference's filter.c compiled unmodified
+           (exists only where oracle/Makefile could see /root/reference, or was prebuilt)
+"""
+import ctypes as C
+import os
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_PATH = os.path.join(ROOT, "oracle", "libqk_oracle.so")
+REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libquisk_filter_ref.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+c_dp = C.POINTER(C.c_double)
+cdp = np.ctypeslib.ndpointer(dtype=np.complex128, flags="C_CONTIGUOUS")
+ddp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+idp = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+# ----------------------------------------------------------------------------- oracle structs
+class OCFir(C.Structure):
+    _fields_ = [("h", c_dp), ("hc", C.c_void_p), ("ntaps", C.c_int), ("decim_index", C.c_int),
+                ("ring", C.c_void_p), ("pos", C.c_int), ("scratch", C.c_void_p), ("nscratch", C.c_int)]
+
+
+class ODFir(C.Structure):
+    _fields_ = OCFir._fields_
+
+
+class OCHB(C.Structure):
+    _fields_ = [("toggle", C.c_int), ("samples", C.c_double * 44), ("center", C.c_double * 22),
+                ("scratch", C.c_void_p), ("nscratch", C.c_int)]
+
+
+class ODHB(C.Structure):
+    _fields_ = [("toggle", C.c_int), ("samples", C.c_double * 22), ("center", C.c_double * 11),
+                ("scratch", C.c_void_p), ("nscratch", C.c_int)]
+
+
+class OAgc(C.Structure):
+    _fields_ = [("max_out", C.c_double), ("sample_rate", C.c_int), ("buf_size", C.c_int),
+                ("index_read", C.c_int), ("index_start", C.c_int), ("is_clipping", C.c_int),
+                ("themax", C.c_double), ("gain", C.c_double), ("delta", C.c_double),
+                ("target_gain", C.c_double), ("time_release", C.c_double), ("ring", C.c_void_p)]
+
+
+class OFrac(C.Structure):
+    _fields_ = [("dindex", C.c_double), ("c", C.c_double * 8)]
+
+
+class OGraph(C.Structure):
+    _fields_ = [("fft_size", C.c_int), ("data_width", C.c_int), ("sample_rate", C.c_int),
+                ("window", c_dp), ("avg", c_dp), ("count", C.c_int), ("meter", C.c_double),
+                ("rx_tune", C.c_int), ("filter_start_offset", C.c_int), ("filter_bandwidth", C.c_int)]
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is not None:
+        return _oracle
+    if not os.path.exists(ORACLE_PATH):
+        raise RuntimeError("oracle library missing: run `make -C oracle` (or __graft_entry__.build())")
+    L = C.CDLL(ORACLE_PATH)
+    P = C.POINTER
+    L.qko_table.restype = c_dp
+    L.qko_table.argtypes = [C.c_char_p, P(C.c_int)]
+    L.qko_cfir_init.argtypes = [P(OCFir), c_dp, C.c_int]
+    L.qko_dfir_init.argtypes = [P(ODFir), c_dp, C.c_int]
+    L.qko_cfir_free.argtypes = [P(OCFir)]
+    L.qko_dfir_free.argtypes = [P(ODFir)]
+    L.qko_filt_tune.argtypes = [P(ODFir), C.c_double, C.c_int]
+    for nm in ("qko_cdecimate", "qko_ccdecimate", "qko_cinterpolate"):
+        getattr(L, nm).argtypes = [cdp, C.c_int, P(OCFir), C.c_int]
+    L.qko_ddecimate.argtypes = [ddp, C.c_int, P(ODFir), C.c_int]
+    L.qko_dinterpolate.argtypes = [ddp, C.c_int, P(ODFir), C.c_int]
+    L.qko_dfilter.argtypes = [ddp, C.c_int, P(ODFir)]
+    L.qko_cinterpdecim.argtypes = [cdp, C.c_int, P(OCFir), C.c_int, C.c_int]
+    L.qko_cdecim2hb45.argtypes = [cdp, C.c_int, P(OCHB)]
+    L.qko_cinterp2hb45.argtypes = [cdp, C.c_int, P(OCHB)]
+    L.qko_dinterp2hb45.argtypes = [ddp, C.c_int, P(ODHB)]
+    L.qko_plan_decimation.argtypes = [C.c_int, P(C.c_int), P(C.c_int), P(C.c_int)]
+    L.qko_decim_rate.argtypes = [C.c_int]
+    L.qko_get_filter_rate.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.qko_rx_new.restype = C.c_void_p
+    L.qko_rx_new.argtypes = [C.c_int, C.c_int]
+    L.qko_rx_free.argtypes = [C.c_void_p]
+    L.qko_rx_set_tune.argtypes = [C.c_void_p, C.c_int]
+    L.qko_rx_set_mode.argtypes = [C.c_void_p, C.c_int]
+    L.qko_rx_set_filter.argtypes = [C.c_void_p, ddp, ddp, C.c_int, C.c_int]
+    L.qko_rx_set_agc.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.qko_rx_process.argtypes = [C.c_void_p, cdp, C.c_int]
+    L.qko_rx_mix.argtypes = [C.c_void_p, cdp, C.c_int]
+    L.qko_rx_decimate.argtypes = [C.c_void_p, cdp, C.c_int]
+    L.qko_rx_demodulate.argtypes = [C.c_void_p, cdp, ddp, C.c_int]
+    L.qko_rx_decim_srate.argtypes = [C.c_void_p]
+    L.qko_rx_filter_srate.argtypes = [C.c_void_p]
+    L.qko_agc_init.argtypes = [P(OAgc), C.c_double, C.c_int]
+    L.qko_agc_free.argtypes = [P(OAgc)]
+    L.qko_agc_process.argtypes = [P(OAgc), cdp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
+    L.qko_fracdecim_init.argtypes = [P(OFrac)]
+    L.qko_fracdecim.argtypes = [P(OFrac), cdp, C.c_int, C.c_double]
+    L.qko_fft.argtypes = [cdp, C.c_int]
+    L.qko_hann_window.argtypes = [ddp, C.c_int]
+    L.qko_graph_init.argtypes = [P(OGraph), C.c_int, C.c_int, C.c_int]
+    L.qko_graph_free.argtypes = [P(OGraph)]
+    L.qko_graph_set_passband.argtypes = [P(OGraph), C.c_int, C.c_int, C.c_int]
+    L.qko_graph_add_frame.argtypes = [P(OGraph), cdp]
+    L.qko_graph_release.argtypes = [P(OGraph), C.c_double, C.c_double, ddp, P(C.c_double)]
+    L.qko_rx_process_many.argtypes = [P(C.c_void_p), C.c_int, cdp, C.c_int, cdp, C.c_long, idp]
+    _oracle = L
+    return L
+
+
+def oracle_table(name):
+    n = C.c_int(0)
+    p = oracle().qko_table(name.encode(), C.byref(n))
+    if not p:
+        raise KeyError(name)
+    return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+
+class OracleRx:
+    """One reference-semantics receiver (quisk_process_samples for bank 0)."""
+
+    def __init__(self, sample_rate, playback_rate=48000, mode=3, tune=0, fi=None, fq=None, bandwidth=0,
+                 agc_gain=80.0, agc_release_time=1.0):
+        self.L = oracle()
+        self.h = self.L.qko_rx_new(sample_rate, playback_rate)
+        self.L.qko_rx_set_mode(self.h, mode)
+        self.L.qko_rx_set_tune(self.h, tune)
+        self.L.qko_rx_set_agc(self.h, agc_gain, agc_release_time)
+        if fi is not None:
+            fi = np.ascontiguousarray(fi, dtype=np.float64)
+            fq = np.ascontiguousarray(fq, dtype=np.float64)
+            assert self.L.qko_rx_set_filter(self.h, fi, fq, len(fi), bandwidth) == 0
+
+    def set_tune(self, hz):
+        self.L.qko_rx_set_tune(self.h, hz)
+
+    def process(self, x):
+        """x: complex128 block (<= 66000); returns the stereo audio block."""
+        buf = np.array(x, dtype=np.complex128, copy=True)
+        cap = max(len(buf), 16)
+        work = np.zeros(max(cap, 2 * cap), dtype=np.complex128)
+        work[:len(buf)] = buf
+        m = self.L.qko_rx_process(self.h, work, len(buf))
+        return work[:m].copy()
+
+    def process_stream(self, x, block):
+        outs = [self.process(x[i:i + block]) for i in range(0, len(x), block)]
+        return np.concatenate(outs) if outs else np.zeros(0, np.complex128)
+
+    def close(self):
+        if self.h:
+            self.L.qko_rx_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------- reference structs
+class RCFilter(C.Structure):      # struct quisk_cFilter, filter.h:1-10
+    _fields_ = [("dCoefs", c_dp), ("cpxCoefs", C.c_void_p), ("nBuf", C.c_int), ("nTaps", C.c_int),
+                ("decim_index", C.c_int), ("cSamples", C.c_void_p), ("ptcSamp", C.c_void_p), ("cBuf", C.c_void_p)]
+
+
+class RDFilter(C.Structure):      # struct quisk_dFilter, filter.h:12-21
+    _fields_ = [("dCoefs", c_dp), ("cpxCoefs", C.c_void_p), ("nBuf", C.c_int), ("nTaps", C.c_int),
+                ("decim_index", C.c_int), ("dSamples", C.c_void_p), ("ptdSamp", C.c_void_p), ("dBuf", C.c_void_p)]
+
+
+class RCHB(C.Structure):          # struct quisk_cHB45Filter, filter.h:23-29
+    _fields_ = [("cBuf", C.c_void_p), ("nBuf", C.c_int), ("toggle", C.c_int),
+                ("samples", C.c_double * 44), ("center", C.c_double * 22)]
+
+
+class RDHB(C.Structure):          # struct quisk_dHB45Filter, filter.h:31-37
+    _fields_ = [("dBuf", C.c_void_p), ("nBuf", C.c_int), ("toggle", C.c_int),
+                ("samples", C.c_double * 22), ("center", C.c_double * 11)]
+
+
+_ref = None
+
+
+def have_ref():
+    return os.path.exists(REF_PATH)
+
+
+def ref():
+    global _ref
+    if _ref is not None:
+        return _ref
+    L = C.CDLL(REF_PATH)
+    P = C.POINTER
+    L.quisk_filt_cInit.argtypes = [P(RCFilter), c_dp, C.c_int]
+    L.quisk_filt_dInit.argtypes = [P(RDFilter), c_dp, C.c_int]
+    L.quisk_filt_tune.argtypes = [P(RDFilter), C.c_double, C.c_int]
+    for nm in ("quisk_cDecimate", "quisk_cCDecimate", "quisk_cInterpolate"):
+        getattr(L, nm).argtypes = [cdp, C.c_int, P(RCFilter), C.c_int]
+    L.quisk_dDecimate.argtypes = [ddp, C.c_int, P(RDFilter), C.c_int]
+    L.quisk_dInterpolate.argtypes = [ddp, C.c_int, P(RDFilter), C.c_int]
+    L.quisk_dFilter.argtypes = [ddp, C.c_int, P(RDFilter)]
+    L.quisk_cInterpDecim.argtypes = [cdp, C.c_int, P(RCFilter), C.c_int, C.c_int]
+    L.quisk_cDecim2HB45.argtypes = [cdp, C.c_int, P(RCHB)]
+    L.quisk_cInterp2HB45.argtypes = [cdp, C.c_int, P(RCHB)]
+    L.quisk_dInterp2HB45.argtypes = [ddp, C.c_int, P(RDHB)]
+    _ref = L
+    return L
+
+
+def ref_table(symbol, n):
+    arr = (C.c_double * n).in_dll(ref(), symbol)
+    return np.array(arr[:], dtype=np.float64)
