@@ -1,0 +1,26 @@
+# Builds the product library (HIP, gfx950) and the checker libraries.
+HIPCC ?= /opt/rocm/bin/hipcc
+CC ?= gcc
+ARCH ?= gfx950
+CSRC = quisk_amd/csrc
+LIB = quisk_amd/libqkengine.so
+HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-value
+
+all: $(LIB) oracle
+
+$(CSRC)/qk_phasor.o: $(CSRC)/qk_phasor.c
+	$(CC) -O2 -ffp-contract=off -fPIC -c -o $@ $<
+
+$(CSRC)/qk_engine.o: $(CSRC)/qk_engine.hip $(CSRC)/qk_kernels.h $(CSRC)/qk_fft.h $(CSRC)/qk_coefs.inc include/qk_engine.h
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $(CSRC)/qk_engine.hip
+
+$(LIB): $(CSRC)/qk_engine.o $(CSRC)/qk_phasor.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(CSRC)/qk_engine.o $(CSRC)/qk_phasor.o -lm
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(LIB) $(CSRC)/*.o
+	$(MAKE) -C oracle clean
+.PHONY: all oracle clean

@@ -1,0 +1,142 @@
+/* qk_engine.h -- C ABI of the MI355X receive-DSP engine (libqkengine.so).
+ *
+ * This is the drop-in boundary for Quisk's receive hot path: the entry points are what the
+ * reference's `_quisk` extension (quisk.c) binds for that path, generalised from the reference's
+ * three demodulator "banks" (MAX_RX_CHANNELS, quisk.c:33) to N independent receivers that share one
+ * wideband I/Q stream.  Plain C types only.  Each declaration cites the reference interface it
+ * replaces (file:line under the reference tree).  INTEGRATION.md shows the binding a maintainer of
+ * the reference would add.
+ *
+ * Threading: like the reference (two threads, no locks), setters may be called from a thread other
+ * than the one that calls qk_process_*; the engine takes a mutex around every entry point, so
+ * setters take effect at the next block boundary.
+ *
+ * All functions return 0 (QK_OK) or a negative error code unless stated otherwise;
+ * qk_last_error() returns a message for the calling thread's last failure.
+ */
+#ifndef QK_ENGINE_H
+#define QK_ENGINE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qk_engine qk_engine;
+
+enum { QK_OK = 0, QK_EINVAL = -1, QK_ENOMEM = -2, QK_EHIP = -3, QK_ERANGE = -4, QK_EUNSUPPORTED = -5 };
+
+/* receive modes: rx_mode_type, quisk.h:48-63 (same numeric values, set_rx_mode passes them through) */
+enum { QK_CWL = 0, QK_CWU = 1, QK_LSB = 2, QK_USB = 3, QK_AM = 4, QK_FM = 5, QK_EXT = 6, QK_DGT_U = 7,
+       QK_DGT_L = 8, QK_DGT_IQ = 9, QK_IMD = 10, QK_FDV_U = 11, QK_FDV_L = 12, QK_DGT_FM = 13 };
+
+typedef struct qk_config {
+    int device;            /* HIP device ordinal */
+    int sample_rate;       /* input I/Q rate, quisk_sound_state.sample_rate (record_app `rate`, quisk.c:5070) */
+    int playback_rate;     /* audio rate: 48000 x {1,2,4,8} (quisk.c:2535-2553) */
+    int n_receivers;       /* number of independent receivers (reference: 3 banks) */
+    int max_block;         /* largest n accepted by qk_process_* (reference: SAMP_BUFFER_SIZE 66000, quisk.h:15) */
+    int fft_size;          /* display FFT size, power of two, or 0 for no spectrum (record_app, quisk.c:5054) */
+    int data_width;        /* graph points returned by qk_get_graph (record_app, quisk.c:5054) */
+    int reserved[8];       /* must be zero */
+} qk_config;
+
+/* record_app (quisk.c:5048-5113): allocates the FFT buffers/window and initialises every filter state
+ * (quisk_process_decimate(NULL), quisk_process_demodulate(NULL), quisk.c:5106-5107). */
+int  qk_create(qk_engine **out, const qk_config *cfg);
+void qk_destroy(qk_engine *e);
+const char *qk_last_error(void);
+const char *qk_version(void);
+
+/* set_tune (quisk.c:4323-4329) for receiver 0 / set_multirx_freq (quisk.c:4438-4448) for the others:
+ * tuning offset in integer Hz from the centre of the I/Q stream.  The running phasor is not reset
+ * (rxTuneVector is a function static, quisk.c:2168). */
+int qk_set_tune(qk_engine *e, int rx, int tune_hz);
+/* set_rx_mode (quisk.c:4262-4269) / set_multirx_mode (quisk.c:4426-4436).  FDV_* and EXT need an external
+ * codec / plug-in and return QK_EUNSUPPORTED. */
+int qk_set_mode(qk_engine *e, int rx, int mode);
+/* set_filters (quisk.c:4192-4235): n I taps and n Q taps of the receive band-pass, bandwidth and lower
+ * edge offset in Hz.  n >= 10001 (MAX_FILTER_SIZE) is an error, as in the reference.  n == 0 = no filter. */
+int qk_set_filters(qk_engine *e, int rx, const double *filt_i, const double *filt_q, int n,
+                   int bandwidth, int start_offset);
+/* set_agc (quisk.c:4184-4190): agcReleaseGain. */
+int qk_set_agc(qk_engine *e, int rx, double release_gain);
+/* agc_release_time (quisk.c:146; from the config file, quisk.c:3833).  Must be set before the first block. */
+int qk_set_agc_release_time(qk_engine *e, double seconds);
+
+/* quisk_process_samples (quisk.h:258, quisk.c:2149-2616), for all receivers at once.
+ * iq: n interleaved (re, im) doubles = C99 `complex double`, in HOST memory (copied in) ... */
+int qk_process_samples(qk_engine *e, const double *iq_host, int n);
+/* ... or already resident in DEVICE memory (no copy; the pointer must stay valid until qk_sync). */
+int qk_process_samples_device(qk_engine *e, const double *iq_dev, int n);
+/* add_rx_samples (quisk.c:2777-2839): n_bytes of interleaved I,Q signed integers of `bytes` (1..4)
+ * per component, little (endian=0) or big endian, left-justified into int32 by the unpack kernel. */
+int qk_process_samples_int(qk_engine *e, const void *raw_host, size_t n_bytes, int bytes, int big_endian);
+int qk_sync(qk_engine *e);
+
+/* Number of stereo output samples receiver rx produced in the last block (the return value of
+ * quisk_process_samples), or a negative error. */
+int qk_audio_count(qk_engine *e, int rx);
+/* Copy the last block's audio of receiver rx (interleaved re=left, im=right doubles) to host memory;
+ * returns the count copied.  cap is in complex samples. */
+int qk_pull_audio(qk_engine *e, int rx, double *dst_host, int cap);
+/* All receivers at once: dst is [n_receivers][stride] complex samples; counts[n_receivers]. */
+int qk_pull_audio_all(qk_engine *e, double *dst_host, size_t stride, int *counts);
+/* Device pointer and stride (in complex samples) of the audio output array, for zero-copy consumers
+ * and for the RCCL gather. */
+int qk_audio_device(qk_engine *e, const double **dev_ptr, size_t *stride);
+
+/* get_graph (quisk.c:4602-4759) with the wall-clock gate (quisk.c:4712) left to the caller: returns the
+ * number of FFT frames averaged since the last release (0 = no data, `out` untouched), writes
+ * data_width dB values and the S-meter value (quisk.c:4728-4737), and clears the average. */
+int qk_get_graph(qk_engine *e, double zoom, double deltaf, double *out, int data_width, double *smeter);
+/* Frames waiting in the average (count_fft, quisk.c:4613) without releasing them. */
+int qk_graph_pending(qk_engine *e);
+/* Device pointer to the last released graph row (data_width doubles), for the RCCL gather. */
+int qk_graph_device(qk_engine *e, const double **dev_ptr);
+
+/* get_filter_rate (quisk.c:2661-2735) and PlanDecimation (quisk.c:1509-1547): pure functions. */
+int qk_get_filter_rate(int sample_rate, int mode, int bandwidth);
+int qk_plan_decimation(int sample_rate, int *decim2, int *decim3, int *decim5);
+/* quisk_decim_srate when quisk_process_decimate returns (quisk.c:1607-1720). */
+int qk_decim_rate(int sample_rate);
+
+/* get_state (quisk.c:2618-2643) keeps error counters; the engine's equivalents: */
+typedef struct qk_stats {
+    int64_t samples_in;        /* total I/Q samples consumed */
+    int64_t blocks;            /* calls to qk_process_* */
+    int64_t fft_frames;        /* display FFT frames transformed */
+    int64_t fft_error;         /* frames dropped (fft_error, quisk.c:38); always 0: the GPU path never drops */
+    double last_block_ms;      /* device time of the last block (HIP events), or 0 when timing is off */
+    double last_kernel_ms[8];  /* device time of the named kernels of the last block: see QK_KT_* */
+} qk_stats;
+enum { QK_KT_FRONTEND = 0, QK_KT_DECIM = 1, QK_KT_DEMOD = 2, QK_KT_AUDIO = 3, QK_KT_AGC = 4, QK_KT_FFT = 5 };
+int qk_get_stats(qk_engine *e, qk_stats *out);
+/* Per-stage HIP-event timing (off by default: the events serialise nothing but cost a few us). */
+int qk_set_timing(qk_engine *e, int on);
+
+/* Stage taps for parity tests (debug): copy the planar output of an internal stream to the host.
+ * which: QK_TAP_*; out: [planes][count] doubles; returns count per plane. */
+enum { QK_TAP_FRONTEND = 0, QK_TAP_DECIM = 1, QK_TAP_DEMOD = 2, QK_TAP_AUDIO48 = 3, QK_TAP_PLAY = 4 };
+int qk_debug_tap(qk_engine *e, int which, int rx, double *out_host, int cap);
+
+/* filter.c drop-ins (filter.h:39-54) for callers that hold their samples in host memory.  The two names
+ * BASELINE.json's north_star uses for them come from later Quisk releases and do not exist in this
+ * snapshot ("two facts"); they are provided as thin aliases:
+ *   quisk_cCplxSampleFilter : real-coefficient FIR over complex samples, decimate by `decim`
+ *                             (quisk_cDecimate, filter.c:180-206; decim 1 = quisk_cFilter, filter.c:349)
+ *   quisk_ccfFilter         : complex-coefficient FIR over complex samples, decimate by `decim`
+ *                             (quisk_cCDecimate, filter.c:208-234; coefficients as quisk_filt_tune makes them)
+ * State is explicit, like the reference's struct quisk_cFilter (filter.h:1-10): `hist` holds the last
+ * ntaps-1 input samples (interleaved), `*phase` the decimation counter.  Samples are processed in place;
+ * the return value is the output count. */
+int quisk_cCplxSampleFilter(double *samples, int count, const double *coefs, int ntaps, int decim,
+                            double *hist, int *phase);
+int quisk_ccfFilter(double *samples, int count, const double *cpx_coefs, int ntaps, int decim,
+                    double *hist, int *phase);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -710,8 +710,8 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
     return n;
 }
 
-int qko_rx_process(qko_rx *rx, qko_cd *x, int n)
-{
+int qko_rx_pre_agc(qko_rx *rx, qko_cd *x, int n)
+{   /* quisk_process_samples up to the AGC (quisk.c:2350-2553): stereo samples at the play rate */
     int i;
     if (n <= 0) return n;
     if (n * 2 > rx->naudio) {                            /* quisk.c:2198-2212 */
@@ -735,8 +735,20 @@ int qko_rx_process(qko_rx *rx, qko_cd *x, int n)
     case 2: n = qko_cinterp2hb45(x, n, &rx->play_hb[0]); break;
     default: break;
     }
+    return n;
+}
+
+void qko_rx_agc(qko_rx *rx, qko_cd *x, int n)
+{   /* quisk.c:2556-2575 */
     qko_agc_process(&rx->agc, x, n, rx->mode == QKO_DGT_IQ, rx->playback_rate, rx->release_gain,
                     rx->release_time, rx->mode == QKO_FM || rx->mode == QKO_DGT_FM);
+}
+
+int qko_rx_process(qko_rx *rx, qko_cd *x, int n)
+{
+    if (n <= 0) return n;
+    n = qko_rx_pre_agc(rx, x, n);
+    qko_rx_agc(rx, x, n);
     return n;
 }
 

@@ -88,6 +88,9 @@ void qko_rx_set_agc(qko_rx *rx, double release_gain, double release_time); /* se
 /* quisk_process_samples (quisk.c:2149-2616), key up, default options: in place, returns the number
  * of stereo output samples written to the head of x.  n <= 66000 like the reference's buffer. */
 int  qko_rx_process(qko_rx *rx, qko_cd *x, int n);
+/* the same in two steps: everything before the AGC (returns the count), then the AGC in place */
+int  qko_rx_pre_agc(qko_rx *rx, qko_cd *x, int n);
+void qko_rx_agc(qko_rx *rx, qko_cd *x, int n);
 /* stages, exposed for per-stage parity tests */
 void qko_rx_mix(qko_rx *rx, qko_cd *x, int n);                         /* quisk.c:2350-2361 */
 int  qko_rx_decimate(qko_rx *rx, qko_cd *x, int n);                    /* quisk.c:1549-1722 */

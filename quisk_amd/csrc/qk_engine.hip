@@ -1,0 +1,1023 @@
+// qk_engine.hip -- host side of the receive-DSP engine: plans the reference's decimation / demodulation
+// chain (quisk_process_decimate, quisk_process_demodulate, quisk_process_samples in quisk.c) for N
+// receivers, owns the streams in HBM and launches the kernels of qk_kernels.h.  Exposes the C ABI of
+// include/qk_engine.h.  No CPU fallback: every entry point that computes needs a HIP device.
+#include "../../include/qk_engine.h"
+#include "qk_kernels.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+extern "C" void qk_phase_step(int tune_hz, int sample_rate, double *re, double *im);
+extern "C" void qk_phase_tables(double pre, double pim, double *C, double *B, double *A, int nA);
+
+#define QK_COEF_TABLE(name, n) static const double name[n]
+#include "qk_coefs.inc"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHECK(expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            return fail(QK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));                     \
+    } while (0)
+
+namespace {
+
+constexpr int FE_CHUNK = 1536;
+constexpr int DEFAULT_TAP_CAP = 1024;
+
+enum StageKind { ST_FIR, ST_INTERP, ST_HBINT, ST_RESAMP, ST_RXF, ST_FMDISC, ST_IIR, ST_FRAC };
+enum ChainClass { CL_SSB = 0, CL_CW, CL_AM, CL_FM, CL_COUNT };
+
+struct Stream {
+    double *d = nullptr;
+    int planes = 1, hist = 0, cap = 0, n = 0;
+    long long rx_stride() const { return (long long)planes * (hist + cap); }
+    StreamView view() const { return StreamView{d, rx_stride(), hist + cap, hist}; }
+};
+
+struct Stage {
+    StageKind kind;
+    int in, out;               // stream indices within the owning chain (in == -1: the chain's input stream)
+    const double *h = nullptr; // device taps
+    int T = 0, D = 1, L = 1;
+    int phase = 0;             // decimation counter / resampler index carried between blocks
+    int rxf_kind = 0, iir_kind = 0;
+    double a0 = 0, a1 = 0, b1 = 0, fs = 0;
+    double *iir_state = nullptr;
+    int timer = -1;            // QK_KT_* bucket
+};
+
+struct Chain {
+    bool built = false;
+    std::vector<Stream> streams;
+    std::vector<Stage> stages;
+    std::vector<int> members;  // receivers in this class
+    int *d_members = nullptr;
+    int aud = -1;              // stream index of the 48 kHz-class mono audio
+    int play = -1;             // stream index of the audio at the playback rate (AGC input)
+    int n_out = 0;             // audio samples of the last block
+    // fractional decimator (cFracDecim, quisk.c:570-613): the position recurrence runs on the host
+    double frac_dindex = 1.0;
+    int *d_frac_idx = nullptr; double *d_frac_pos = nullptr; int frac_cap = 0;
+};
+
+struct DevTables { std::vector<double> host; double *dev = nullptr; };
+
+}  // namespace
+
+struct qk_engine {
+    qk_config cfg{};
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    int nrx = 0, S = 0, tap_cap = DEFAULT_TAP_CAP;
+    int fe_rate = 0, decim_srate = 0;
+    int rate_case = 0;
+    // input
+    double2 *d_in = nullptr;
+    unsigned char *d_raw = nullptr; size_t raw_cap = 0;
+    // mixer
+    int H = 0, nA = 0;
+    double2 *d_mixhist[2] = {nullptr, nullptr}, *d_v0[2] = {nullptr, nullptr};
+    double2 *d_tabA = nullptr, *d_tabB = nullptr, *d_tabC = nullptr;
+    int *d_mix_on = nullptr;
+    int pp = 0;                // ping-pong selector
+    long long N0 = 0;
+    std::vector<int> tune, mode, cls;
+    // coefficient tables
+    double *d_coefs = nullptr;
+    const double *h_dec2 = nullptr, *h_dec3 = nullptr, *h_dec5 = nullptr, *h_rs65 = nullptr, *h_hbdec = nullptr,
+                 *h_s53 = nullptr, *h_s111 = nullptr, *h_s133 = nullptr, *h_s167 = nullptr, *h_s185 = nullptr,
+                 *h_a24p3 = nullptr, *h_a24p4 = nullptr, *h_a24p6 = nullptr, *h_fmhp = nullptr;
+    // front chain (shared by all receivers): stream 0 = front-end output
+    Chain front;
+    Chain cls_chain[CL_COUNT];
+    // per receiver
+    double *d_taps = nullptr; int *d_ntaps = nullptr, *d_mode = nullptr; double *d_release_gain = nullptr;
+    std::vector<int> ntaps, bandwidth, start_offset;
+    AgcState *d_agc = nullptr; double *d_gains = nullptr; int gain_stride = 0;
+    int *d_agc_started = nullptr; std::vector<char> agc_started;    // per receiver: has process_agc run once?
+    double agc_release_time = 1.0;
+    // output
+    double2 *d_out = nullptr; size_t out_stride = 0;
+    std::vector<int> out_count;
+    // stats / timing
+    qk_stats stats{};
+    bool timing = false;
+    hipEvent_t ev[16]{};
+    bool ev_used[16]{};
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------- planning (pure)
+int plan_decimation(int rate, int *d2, int *d3, int *d5)
+{   // PlanDecimation, quisk.c:1509-1547
+    int best = rate, b2 = 0, b3 = 0, b5 = 0;
+    for (int i2 = 0; i2 <= 6; i2++)
+        for (int i3 = 0; i3 <= 3; i3++)
+            for (int i5 = 0; i5 <= 3; i5++) {
+                int r = rate;
+                for (int i = 0; i < i2; i++) r /= 2;
+                for (int i = 0; i < i3; i++) r /= 3;
+                for (int i = 0; i < i5; i++) r /= 5;
+                if (r >= 48000 && r < best) { b2 = i2; b3 = i3; b5 = i5; best = r; }
+            }
+    if (best >= 50000) best = best * 24 / 25;
+    if (d2) { *d2 = b2; *d3 = b3; *d5 = b5; }
+    return best;
+}
+int rate_case_of(int rate) { return (rate + 100) / 1000; }
+int decim_rate(int rate)
+{
+    switch (rate_case_of(rate)) {
+    case 41: return 48000;
+    case 53: return rate;
+    case 111: case 133: return rate / 2;
+    case 185: return rate / 3;
+    case 370: return rate / 6;
+    case 740: return rate / 12;
+    case 1333: return rate / 24;
+    }
+    int d2, d3, d5, r = rate;
+    plan_decimation(rate, &d2, &d3, &d5);
+    for (int i = 0; i < d2; i++) r /= 2;
+    for (int i = 0; i < d3; i++) r /= 3;
+    for (int i = 0; i < d5; i++) r /= 5;
+    if (r >= 50000) r = r * 24 / 25;
+    return r;
+}
+int filter_rate(int rate, int mode, int bw)
+{   // get_filter_rate, quisk.c:2661-2735 (case 41 falls through to case 53 there)
+    int decim;
+    switch (rate_case_of(rate)) {
+    case 41: case 53: decim = rate; break;
+    case 111: case 133: decim = rate / 2; break;
+    case 185: decim = rate / 3; break;
+    case 370: decim = rate / 6; break;
+    case 740: decim = rate / 12; break;
+    case 1333: decim = rate / 24; break;
+    default: decim = plan_decimation(rate, nullptr, nullptr, nullptr); break;
+    }
+    switch (mode) {
+    case QK_CWL: case QK_CWU: return decim / 8;
+    case QK_AM: return decim / 2;
+    case QK_FM: case QK_DGT_FM: case QK_DGT_IQ: return decim;
+    case QK_DGT_U: case QK_DGT_L: return bw < 3000 ? decim / 8 : decim;
+    case QK_FDV_U: case QK_FDV_L: return 8000;
+    default: return decim / 4;
+    }
+}
+
+int class_of_mode(int mode)
+{
+    switch (mode) {
+    case QK_CWL: case QK_CWU: return CL_CW;
+    case QK_AM: return CL_AM;
+    case QK_FM: case QK_DGT_FM: return CL_FM;
+    case QK_LSB: case QK_USB: case QK_IMD: return CL_SSB;
+    default: return -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------- chain building
+struct ChainBuilder {
+    Chain &c; int in_cap; int cur; int cur_cap;
+    ChainBuilder(Chain &ch, int input_cap) : c(ch), in_cap(input_cap), cur(-1), cur_cap(input_cap) {}
+    int new_stream(int planes, int cap)
+    {
+        Stream s; s.planes = planes; s.cap = cap + 8; s.hist = 0;
+        c.streams.push_back(s);
+        return (int)c.streams.size() - 1;
+    }
+    void need_hist(int stream, int h)   // stream -1 is the chain input, owned by the caller
+    {
+        if (stream >= 0) c.streams[stream].hist = std::max(c.streams[stream].hist, (h + 1) & ~1);
+        else in_hist = std::max(in_hist, (h + 1) & ~1);
+    }
+    int in_hist = 0;
+    Stage &add(StageKind k, int planes_out, int cap_out)
+    {
+        Stage st; st.kind = k; st.in = cur; st.out = new_stream(planes_out, cap_out);
+        c.stages.push_back(st);
+        cur = st.out; cur_cap = cap_out;
+        return c.stages.back();
+    }
+    void fir(const double *h, int T, int D, int planes, int timer)
+    {
+        need_hist(cur, T - 1);
+        Stage &s = add(ST_FIR, planes, cur_cap / D + 2);
+        s.h = h; s.T = T; s.D = D; s.timer = timer;
+    }
+    void interp(const double *h, int T, int L, int timer)
+    {
+        need_hist(cur, T / L - 1);
+        Stage &s = add(ST_INTERP, 1, cur_cap * L + 2);
+        s.h = h; s.T = T; s.L = L; s.timer = timer;
+    }
+    void hbint(int planes, int timer)
+    {
+        need_hist(cur, 21);
+        Stage &s = add(ST_HBINT, planes, cur_cap * 2 + 2);
+        s.timer = timer;
+    }
+    void resamp(const double *h, int T, int L, int D, int timer)
+    {
+        need_hist(cur, T / L - 1);
+        Stage &s = add(ST_RESAMP, 2, (int)((long long)cur_cap * L / D) + 4);
+        s.h = h; s.T = T; s.L = L; s.D = D; s.timer = timer;
+    }
+};
+
+}  // namespace
+
+// =================================================================================== engine methods
+static void free_chain(Chain &c)
+{
+    for (auto &s : c.streams) if (s.d) hipFree(s.d);
+    for (auto &st : c.stages) if (st.iir_state) hipFree(st.iir_state);
+    if (c.d_members) hipFree(c.d_members);
+    if (c.d_frac_idx) hipFree(c.d_frac_idx);
+    if (c.d_frac_pos) hipFree(c.d_frac_pos);
+    c = Chain();
+}
+
+static int alloc_chain_streams(qk_engine *e, Chain &c)
+{
+    for (auto &s : c.streams) {
+        size_t bytes = (size_t)e->nrx * s.rx_stride() * sizeof(double);
+        HIPCHECK(hipMalloc(&s.d, bytes));
+        HIPCHECK(hipMemsetAsync(s.d, 0, bytes, e->stream));
+    }
+    return QK_OK;
+}
+
+// Front chain: everything quisk_process_decimate does after the fused half-bands (quisk.c:1607-1720).
+static int build_front(qk_engine *e)
+{
+    const int rate = e->cfg.sample_rate;
+    int d2 = 0, d3 = 0, d5 = 0;
+    e->rate_case = rate_case_of(rate);
+    Chain &c = e->front;
+    int S = 0;
+    struct Fir { const double *h; int T, D; };
+    std::vector<Fir> firs;
+    bool resample = false;
+    switch (e->rate_case) {
+    case 41: break;
+    case 53: firs.push_back({e->h_s53, 55, 1}); break;
+    case 111: firs.push_back({e->h_s111, 114, 2}); break;
+    case 133: firs.push_back({e->h_s133, 136, 2}); break;
+    case 185: firs.push_back({e->h_s185, 189, 3}); break;
+    case 370: S = 1; firs.push_back({e->h_s185, 189, 3}); break;
+    case 740: S = 2; firs.push_back({e->h_s185, 189, 3}); break;
+    case 1333: S = 3; firs.push_back({e->h_s167, 174, 3}); break;
+    default: {
+        plan_decimation(rate, &d2, &d3, &d5);
+        S = std::min(std::max(d2 - 1, 0), 5);
+        for (int i = 0; i < d3; i++) firs.push_back({e->h_dec3, 147, 3});
+        for (int i = 0; i < d5; i++) firs.push_back({e->h_dec5, 245, 5});
+        if (d2 > 0) firs.push_back({e->h_dec2, 98, 2});
+        int r = rate;
+        for (int i = 0; i < d2; i++) r /= 2;
+        for (int i = 0; i < d3; i++) r /= 3;
+        for (int i = 0; i < d5; i++) r /= 5;
+        resample = r >= 50000;
+        if (resample && d5 >= 3)
+            return fail(QK_EUNSUPPORTED, "sample rate whose plan uses three /5 stages and the 24/25 resampler "
+                                         "(the reference shares one filter state between them, quisk.c:1713)");
+        break;
+    }
+    }
+    e->S = S;
+    e->decim_srate = decim_rate(rate);
+    ChainBuilder b(c, e->cfg.max_block);
+    // stream 0: front-end output (mixer + S half-bands)
+    b.cur = b.new_stream(2, (e->cfg.max_block >> S) + 2);
+    b.cur_cap = (e->cfg.max_block >> S) + 2;
+    for (auto &f : firs) b.fir(f.h, f.T, f.D, 2, QK_KT_DECIM);
+    if (resample) {
+        b.resamp(e->h_rs65, 125, 6, 5, QK_KT_DECIM);
+        b.resamp(e->h_dec5, 245, 4, 5, QK_KT_DECIM);
+    }
+    c.aud = b.cur;      // "aud" of the front chain = the decimated complex stream every class reads
+    c.built = true;
+    return QK_OK;
+}
+
+static int build_class(qk_engine *e, int cl)
+{
+    Chain &c = e->cls_chain[cl];
+    Stream &dec = e->front.streams[e->front.aud];
+    ChainBuilder b(c, dec.cap);
+    const int T_A = QK_KT_DEMOD, T_B = QK_KT_AUDIO;
+    auto rxf = [&](int kind, int planes_out) {
+        b.need_hist(b.cur, e->tap_cap);
+        Stage &s = b.add(ST_RXF, planes_out, b.cur_cap + 2);
+        s.rxf_kind = kind; s.timer = T_A;
+    };
+    auto iir = [&](int kind) -> int {
+        Stage &s = b.add(ST_IIR, 1, b.cur_cap + 2);
+        s.iir_kind = kind; s.timer = T_B;
+        if (kind == 1) {    // de-emphasis coefficients, quisk.c:1764-1768
+            const double www = tan(M_PI * 300.0 / 48000), nnn = 1.0 / (1.0 + www);
+            s.a0 = www * nnn; s.a1 = s.a0; s.b1 = nnn * (www - 1.0);
+        }
+        HIPCHECK(hipMalloc(&s.iir_state, sizeof(double) * 2 * e->nrx));
+        HIPCHECK(hipMemsetAsync(s.iir_state, 0, sizeof(double) * 2 * e->nrx, e->stream));
+        return QK_OK;
+    };
+    int rc = QK_OK;
+    switch (cl) {
+    case CL_SSB:    // quisk.c:1817-1862
+        b.fir(e->h_hbdec, 43, 2, 2, T_A);
+        b.fir(e->h_dec2, 98, 2, 2, T_A);
+        rxf(0, 1);
+        b.interp(e->h_a24p4, 50, 2, T_B);
+        b.hbint(1, T_B);
+        break;
+    case CL_CW:     // quisk.c:1779-1816
+        b.fir(e->h_hbdec, 43, 2, 2, T_A);
+        b.fir(e->h_hbdec, 43, 2, 2, T_A);
+        b.fir(e->h_dec2, 98, 2, 2, T_A);
+        rxf(0, 1);
+        b.interp(e->h_a24p4, 50, 2, T_B);
+        b.hbint(1, T_B);
+        b.hbint(1, T_B);
+        break;
+    case CL_AM:     // quisk.c:1863-1886
+        b.fir(e->h_dec2, 98, 2, 2, T_A);
+        rxf(1, 1);
+        rc = iir(0);
+        b.fir(e->h_a24p6, 36, 1, 1, T_B);
+        b.hbint(1, T_B);
+        break;
+    case CL_FM: {   // quisk.c:1887-1921
+        rxf(2, 2);
+        b.need_hist(b.cur, 1);
+        Stage &s = b.add(ST_FMDISC, 1, b.cur_cap + 2);
+        s.fs = e->decim_srate; s.timer = T_A;
+        rc = iir(1);
+        b.fir(e->h_a24p3, 100, 2, 1, T_B);
+        b.fir(e->h_fmhp, 309, 1, 1, T_B);
+        b.hbint(1, T_B);
+        break;
+    }
+    }
+    if (rc != QK_OK) return rc;
+    c.aud = b.cur;
+    // tail: fractional decimator when the decimated rate is not 48000 (quisk.c:2528-2532) ...
+    if (e->decim_srate != 48000) {
+        b.need_hist(b.cur, 3);
+        Stage &s = b.add(ST_FRAC, 1, b.cur_cap + 2);
+        s.timer = T_B;
+        c.frac_cap = b.cur_cap + 8;
+        HIPCHECK(hipMalloc(&c.d_frac_idx, sizeof(int) * c.frac_cap));
+        HIPCHECK(hipMalloc(&c.d_frac_pos, sizeof(double) * c.frac_cap));
+    }
+    // ... then interpolation to the play rate (quisk.c:2535-2553); mono, so one plane carries both channels
+    for (int r = e->cfg.playback_rate / 48000; r > 1; r /= 2) b.hbint(1, T_B);
+    c.play = b.cur;
+    b.need_hist(b.cur, e->cfg.playback_rate * 15 / 1000);       // AGC_DELAY, quisk.c:30, 2036
+    // the class input is the front chain's output stream
+    Stream &in = e->front.streams[e->front.aud];
+    if (in.d == nullptr) in.hist = std::max(in.hist, b.in_hist);
+    else if (in.hist < b.in_hist) return fail(QK_EINVAL, "internal: front stream history too small");
+    rc = alloc_chain_streams(e, c);
+    if (rc != QK_OK) return rc;
+    if (cl == CL_FM) {
+        // fm_1 starts at 10 + 0i (quisk.c:1763): it is the history sample in front of the first block
+        Stream &f = c.streams[c.stages[0].out];
+        std::vector<double> ten((size_t)e->nrx, 10.0);
+        for (int r = 0; r < e->nrx; r++)
+            HIPCHECK(hipMemcpyAsync(f.d + (long long)r * f.rx_stride() + f.hist - 1, &ten[r], sizeof(double),
+                                    hipMemcpyHostToDevice, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    }
+    HIPCHECK(hipMalloc(&c.d_members, sizeof(int) * e->nrx));
+    c.built = true;
+    return QK_OK;
+}
+
+static int upload_members(qk_engine *e)
+{
+    for (int cl = 0; cl < CL_COUNT; cl++) e->cls_chain[cl].members.clear();
+    for (int r = 0; r < e->nrx; r++) e->cls_chain[e->cls[r]].members.push_back(r);
+    for (int cl = 0; cl < CL_COUNT; cl++) {
+        Chain &c = e->cls_chain[cl];
+        if (c.members.empty()) continue;
+        if (!c.built) { int rc = build_class(e, cl); if (rc != QK_OK) return rc; }
+        HIPCHECK(hipMemcpyAsync(c.d_members, c.members.data(), sizeof(int) * c.members.size(),
+                                hipMemcpyHostToDevice, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));      // members vector may be rebuilt right after
+    }
+    return QK_OK;
+}
+
+static int upload_tune(qk_engine *e, int rx)
+{
+    double pre, pim;
+    qk_phase_step(e->tune[rx], e->cfg.sample_rate, &pre, &pim);
+    std::vector<double> C(128), B(128), A((size_t)2 * e->nA);
+    qk_phase_tables(pre, pim, C.data(), B.data(), A.data(), e->nA);
+    const int on = e->tune[rx] != 0;
+    HIPCHECK(hipMemcpyAsync(e->d_tabC + (size_t)rx * 64, C.data(), 128 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipMemcpyAsync(e->d_tabB + (size_t)rx * 64, B.data(), 128 * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipMemcpyAsync(e->d_tabA + (size_t)rx * e->nA, A.data(), (size_t)2 * e->nA * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipMemcpyAsync(e->d_mix_on + rx, &on, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return QK_OK;
+}
+
+static const double *push_table(DevTables &t, const double *src, int n)
+{
+    size_t off = t.host.size();
+    t.host.insert(t.host.end(), src, src + n);
+    if (t.host.size() & 1) t.host.push_back(0.0);
+    return reinterpret_cast<const double *>(off);      // offset, turned into a pointer after upload
+}
+
+static int engine_init(qk_engine *e)
+{
+    const qk_config &cfg = e->cfg;
+    HIPCHECK(hipSetDevice(cfg.device));
+    HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->nrx = cfg.n_receivers;
+    // coefficient tables
+    DevTables T;
+    double hb43[43] = {0};
+    static const double c12[12] = { HB_C0, HB_C1, HB_C2, HB_C3, HB_C4, HB_C5, HB_C6, HB_C7, HB_C8, HB_C9, HB_C10, HB_C11 };
+    for (int k = 0; k < 11; k++) { hb43[2 * k] = c12[k]; hb43[42 - 2 * k] = c12[k]; }
+    hb43[21] = c12[11];
+    const double *o_dec2 = push_table(T, qk_h_dec2_98, 98), *o_dec3 = push_table(T, qk_h_dec3_147, 147),
+                 *o_dec5 = push_table(T, qk_h_dec5_245, 245), *o_rs65 = push_table(T, qk_h_rs65_125, 125),
+                 *o_hb = push_table(T, hb43, 43), *o_s53 = push_table(T, qk_h_sdriq53_55, 55),
+                 *o_s111 = push_table(T, qk_h_sdriq111_114, 114), *o_s133 = push_table(T, qk_h_sdriq133_136, 136),
+                 *o_s167 = push_table(T, qk_h_sdriq167_174, 174), *o_s185 = push_table(T, qk_h_sdriq185_189, 189),
+                 *o_a3 = push_table(T, qk_h_aud24p3_100, 100), *o_a4 = push_table(T, qk_h_aud24p4_50, 50),
+                 *o_a6 = push_table(T, qk_h_aud24p6_36, 36), *o_fm = push_table(T, qk_h_fmhp_309, 309);
+    HIPCHECK(hipMalloc(&e->d_coefs, T.host.size() * sizeof(double)));
+    HIPCHECK(hipMemcpy(e->d_coefs, T.host.data(), T.host.size() * sizeof(double), hipMemcpyHostToDevice));
+#define FIX(dst, off) e->dst = e->d_coefs + reinterpret_cast<size_t>(off)
+    FIX(h_dec2, o_dec2); FIX(h_dec3, o_dec3); FIX(h_dec5, o_dec5); FIX(h_rs65, o_rs65); FIX(h_hbdec, o_hb);
+    FIX(h_s53, o_s53); FIX(h_s111, o_s111); FIX(h_s133, o_s133); FIX(h_s167, o_s167); FIX(h_s185, o_s185);
+    FIX(h_a24p3, o_a3); FIX(h_a24p4, o_a4); FIX(h_a24p6, o_a6); FIX(h_fmhp, o_fm);
+#undef FIX
+    int rc = build_front(e);
+    if (rc != QK_OK) return rc;
+    // mixer state
+    e->H = (44 << e->S) + (1 << e->S) + 64;
+    e->nA = (cfg.max_block >> 12) + 2;
+    const size_t nrx = e->nrx;
+    for (int i = 0; i < 2; i++) {
+        HIPCHECK(hipMalloc(&e->d_mixhist[i], nrx * e->H * sizeof(double2)));
+        HIPCHECK(hipMemset(e->d_mixhist[i], 0, nrx * e->H * sizeof(double2)));
+        HIPCHECK(hipMalloc(&e->d_v0[i], nrx * sizeof(double2)));
+    }
+    std::vector<double2> ones(nrx, make_double2(1.0, 0.0));     // rxTuneVector = 1 (quisk.c:2168)
+    HIPCHECK(hipMemcpy(e->d_v0[0], ones.data(), nrx * sizeof(double2), hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&e->d_tabA, nrx * e->nA * sizeof(double2)));
+    HIPCHECK(hipMalloc(&e->d_tabB, nrx * 64 * sizeof(double2)));
+    HIPCHECK(hipMalloc(&e->d_tabC, nrx * 64 * sizeof(double2)));
+    HIPCHECK(hipMalloc(&e->d_mix_on, nrx * sizeof(int)));
+    HIPCHECK(hipMemset(e->d_mix_on, 0, nrx * sizeof(int)));
+    HIPCHECK(hipMalloc(&e->d_in, (size_t)cfg.max_block * sizeof(double2)));
+    e->tune.assign(nrx, 0); e->mode.assign(nrx, QK_USB); e->cls.assign(nrx, CL_SSB);
+    e->ntaps.assign(nrx, 0); e->bandwidth.assign(nrx, 0); e->start_offset.assign(nrx, 0);
+    e->out_count.assign(nrx, 0);
+    for (size_t r = 0; r < nrx; r++) { rc = upload_tune(e, (int)r); if (rc != QK_OK) return rc; }
+    // per-receiver parameters
+    HIPCHECK(hipMalloc(&e->d_taps, nrx * 2 * e->tap_cap * sizeof(double)));
+    HIPCHECK(hipMemset(e->d_taps, 0, nrx * 2 * e->tap_cap * sizeof(double)));
+    HIPCHECK(hipMalloc(&e->d_ntaps, nrx * sizeof(int)));
+    HIPCHECK(hipMemset(e->d_ntaps, 0, nrx * sizeof(int)));
+    HIPCHECK(hipMalloc(&e->d_mode, nrx * sizeof(int)));
+    HIPCHECK(hipMemcpy(e->d_mode, e->mode.data(), nrx * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<double> rel(nrx, 80.0);                          // agcReleaseGain, quisk.c:145
+    HIPCHECK(hipMalloc(&e->d_release_gain, nrx * sizeof(double)));
+    HIPCHECK(hipMemcpy(e->d_release_gain, rel.data(), nrx * sizeof(double), hipMemcpyHostToDevice));
+    // AGC state as process_agc initialises it (quisk.c:2038-2044)
+    std::vector<AgcState> ag(nrx);
+    for (auto &a : ag) { a.themax = 1.0; a.gain = 100; a.delta = 0; a.target_gain = 100; a.index_read = a.index_start = a.is_clipping = a.pad = 0; }
+    HIPCHECK(hipMalloc(&e->d_agc, nrx * sizeof(AgcState)));
+    HIPCHECK(hipMemcpy(e->d_agc, ag.data(), nrx * sizeof(AgcState), hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&e->d_agc_started, nrx * sizeof(int)));
+    HIPCHECK(hipMemset(e->d_agc_started, 0, nrx * sizeof(int)));
+    e->agc_started.assign(nrx, 0);
+    // output: the audio of one block at the play rate
+    const long long per_block = (long long)cfg.max_block * cfg.playback_rate / cfg.sample_rate + 64;
+    e->out_stride = (size_t)((per_block + 63) & ~63LL);
+    e->gain_stride = (int)e->out_stride;
+    HIPCHECK(hipMalloc(&e->d_out, nrx * e->out_stride * sizeof(double2)));
+    HIPCHECK(hipMemset(e->d_out, 0, nrx * e->out_stride * sizeof(double2)));
+    HIPCHECK(hipMalloc(&e->d_gains, nrx * e->gain_stride * sizeof(double)));
+    // class chains are built when a receiver first enters the class (all receivers start as USB).  Their
+    // input is the front chain's last stream: give it the largest history any class reads back
+    // (the receive band-pass of the FM class reads it directly; the others put a 98-tap FIR first).
+    {
+        Stream &dec = e->front.streams[e->front.aud];
+        dec.hist = std::max(dec.hist, (std::max(e->tap_cap, 98) + 1) & ~1);
+    }
+    rc = alloc_chain_streams(e, e->front);
+    if (rc != QK_OK) return rc;
+    rc = upload_members(e);
+    if (rc != QK_OK) return rc;
+    for (int i = 0; i < 16; i++) HIPCHECK(hipEventCreate(&e->ev[i]));
+    HIPCHECK(hipDeviceSynchronize());
+    return QK_OK;
+}
+
+// ---------------------------------------------------------------------------------- per-block work
+namespace {
+struct Timer {
+    qk_engine *e; int bucket; bool on;
+    Timer(qk_engine *en, int b) : e(en), bucket(b), on(en->timing && b >= 0 && b < 8)
+    {
+        if (on && !e->ev_used[bucket]) hipEventRecord(e->ev[2 * bucket], e->stream);   // first start ... last end
+    }
+    ~Timer() { if (on) { hipEventRecord(e->ev[2 * bucket + 1], e->stream); e->ev_used[bucket] = true; } }
+};
+}  // namespace
+
+static inline dim3 grid1(int n, int planes, int nz) { return dim3((unsigned)((n + 255) / 256), (unsigned)planes, (unsigned)nz); }
+
+// run one chain over `nlist` receivers; `input` is the stream feeding stage.in == -1
+static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_list, int nlist)
+{
+    for (auto &st : c.stages) {
+        const Stream &in = st.in < 0 ? input : c.streams[st.in];
+        Stream &out = c.streams[st.out];
+        const int n_in = in.n;
+        switch (st.kind) {
+        case ST_FIR: {
+            const int n_out = (st.phase + n_in) / st.D;
+            const int first = st.D - 1 - st.phase;
+            st.phase = (st.phase + n_in) % st.D;
+            out.n = n_out;
+            if (n_out > 0) {
+                FirArgs a{in.view(), out.view(), st.h, st.T, st.D, first, n_out, d_list, 0};
+                Timer tm(e, st.timer);
+                hipLaunchKernelGGL(k_fir_decim, grid1(n_out, in.planes, nlist), dim3(256), 0, e->stream, a);
+            }
+            break;
+        }
+        case ST_INTERP: {
+            out.n = n_in * st.L;
+            if (out.n > 0) {
+                InterpArgs a{in.view(), out.view(), st.h, st.T, st.L, n_in, d_list};
+                Timer tm(e, st.timer);
+                hipLaunchKernelGGL(k_interp, grid1(out.n, 1, nlist), dim3(256), 0, e->stream, a);
+            }
+            break;
+        }
+        case ST_HBINT: {
+            out.n = n_in * 2;
+            if (n_in > 0) {
+                HbInterpArgs a{in.view(), out.view(), n_in, d_list};
+                Timer tm(e, st.timer);
+                hipLaunchKernelGGL(k_hb_interp, grid1(n_in, in.planes, nlist), dim3(256), 0, e->stream, a);
+            }
+            break;
+        }
+        case ST_RESAMP: {
+            const long long span = (long long)n_in * st.L;
+            const int n_out = span > st.phase ? (int)((span - st.phase + st.D - 1) / st.D) : 0;
+            const int idx0 = st.phase;
+            st.phase = (int)(st.phase + (long long)n_out * st.D - span);
+            out.n = n_out;
+            if (n_out > 0) {
+                ResampArgs a{in.view(), out.view(), st.h, st.T, st.L, st.D, idx0, n_out, d_list};
+                Timer tm(e, st.timer);
+                hipLaunchKernelGGL(k_resample, grid1(n_out, 2, nlist), dim3(256), 0, e->stream, a);
+            }
+            break;
+        }
+        case ST_RXF: {
+            out.n = n_in;
+            if (n_in > 0) {
+                RxfArgs a{in.view(), out.view(), e->d_taps, e->d_ntaps, e->d_mode, e->tap_cap, n_in, st.rxf_kind, d_list};
+                Timer tm(e, st.timer);
+                hipLaunchKernelGGL(k_rxfilter, grid1(n_in, 1, nlist), dim3(256), 0, e->stream, a);
+            }
+            break;
+        }
+        case ST_FMDISC: {
+            out.n = n_in;
+            if (n_in > 0) {
+                FmDiscArgs a{in.view(), out.view(), n_in, st.fs, d_list};
+                Timer tm(e, st.timer);
+                hipLaunchKernelGGL(k_fm_disc, grid1(n_in, 1, nlist), dim3(256), 0, e->stream, a);
+            }
+            break;
+        }
+        case ST_IIR: {
+            out.n = n_in;
+            if (n_in > 0) {
+                IirArgs a{in.view(), out.view(), n_in, st.iir_kind, st.a0, st.a1, st.b1, st.iir_state, d_list, nlist};
+                Timer tm(e, st.timer);
+                hipLaunchKernelGGL(k_serial_iir, dim3((nlist + 63) / 64), dim3(64), 0, e->stream, a);
+            }
+            break;
+        }
+        case ST_FRAC:
+            return fail(QK_EUNSUPPORTED, "fractional decimator stage not implemented yet");
+        }
+    }
+    return QK_OK;
+}
+
+static void add_tails(TailArgs &ta, Chain &c)
+{
+    for (auto &s : c.streams) {
+        if (s.hist <= 0 || s.n <= 0) continue;
+        if (ta.count >= QK_MAX_TAILS) break;
+        ta.t[ta.count++] = TailDesc{s.d, s.rx_stride(), s.hist + s.cap, s.planes, s.hist, s.n};
+    }
+}
+
+template <int S>
+static void launch_frontend(qk_engine *e, const FrontArgs &fa, int nspans)
+{
+    const size_t lds = FeLayout<FE_CHUNK>::total(S) * sizeof(double);
+    hipLaunchKernelGGL((k_frontend<S, FE_CHUNK>), dim3(nspans, e->nrx), dim3(FE_THREADS), lds, e->stream, fa);
+}
+
+static int process_device(qk_engine *e, const double2 *x, int n)
+{
+    if (n < 0 || n > e->cfg.max_block) return fail(QK_ERANGE, "block larger than max_block");
+    if (n == 0) { for (auto &c : e->out_count) c = 0; return QK_OK; }
+    for (int i = 0; i < 8; i++) e->ev_used[i] = false;
+    hipEvent_t ev_b0 = e->ev[14], ev_b1 = e->ev[15];
+    if (e->timing) hipEventRecord(ev_b0, e->stream);
+    const int S = e->S;
+    Chain &F = e->front;
+    // ---- front end ----
+    FrontArgs fa{};
+    fa.x = x; fa.n = n; fa.N0 = e->N0;
+    fa.hist = e->d_mixhist[e->pp]; fa.H = e->H;
+    fa.mt = MixTables{e->d_tabA, e->d_tabB, e->d_tabC, e->d_v0[e->pp], e->d_mix_on, e->nA};
+    fa.out = F.streams[0].view();
+    fa.J0 = e->N0 >> S;
+    fa.g_lo0 = fa.J0 << S;
+    fa.g_end = ((e->N0 + n) >> S) << S;
+    const long long consumed = fa.g_end - fa.g_lo0;
+    F.streams[0].n = (int)(consumed >> S);
+    {
+        Timer tm(e, QK_KT_FRONTEND);
+        if (S == 0) {
+            hipLaunchKernelGGL(k_mix_only, dim3((n + 255) / 256, e->nrx), dim3(256), 0, e->stream, fa);
+        } else if (consumed > 0) {
+            // spans: enough workgroups to fill 256 CUs several times over, but long enough that the warm-up
+            // (44 * 2^S samples per span) stays a small fraction
+            const long long unit = FE_CHUNK;
+            long long want = std::max(1LL, (long long)(2048 / std::max(1, e->nrx)));
+            long long span = (consumed + want - 1) / want;
+            span = std::max(span, 4 * unit);
+            span = (span + unit - 1) / unit * unit;
+            const int nspans = (int)((consumed + span - 1) / span);
+            fa.span_len = (int)span;
+            switch (S) {
+            case 1: launch_frontend<1>(e, fa, nspans); break;
+            case 2: launch_frontend<2>(e, fa, nspans); break;
+            case 3: launch_frontend<3>(e, fa, nspans); break;
+            case 4: launch_frontend<4>(e, fa, nspans); break;
+            default: launch_frontend<5>(e, fa, nspans); break;
+            }
+        }
+    }
+    if (S > 0)
+        hipLaunchKernelGGL(k_mixhist_update, dim3((e->H + 255) / 256, e->nrx), dim3(256), 0, e->stream, fa,
+                           e->d_mixhist[e->pp ^ 1], e->d_v0[e->pp ^ 1]);
+    else
+        hipLaunchKernelGGL(k_mixhist_update, dim3(1, e->nrx), dim3(256), 0, e->stream, fa,
+                           e->d_mixhist[e->pp ^ 1], e->d_v0[e->pp ^ 1]);
+    e->pp ^= 1;
+    e->N0 += n;
+    // ---- remaining integer decimation, all receivers ----
+    int rc = run_chain(e, F, F.streams[0], nullptr, e->nrx);
+    if (rc != QK_OK) return rc;
+    const Stream &dec = F.streams[F.aud];
+    // ---- per class: demodulate, audio chain, AGC ----
+    for (int cl = 0; cl < CL_COUNT; cl++) {
+        Chain &c = e->cls_chain[cl];
+        const int nl = (int)c.members.size();
+        if (!nl) continue;
+        rc = run_chain(e, c, dec, c.d_members, nl);
+        if (rc != QK_OK) return rc;
+        Stream &play = c.streams[c.play];
+        const int m = play.n;
+        c.n_out = m;
+        if (m > (int)e->out_stride) return fail(QK_ERANGE, "internal: audio block exceeds the output stride");
+        if (m > 0) {
+            const int rate = e->cfg.playback_rate;
+            AgcArgs a{};
+            a.in = play.view(); a.gains = e->d_gains; a.gain_stride = e->gain_stride; a.n = m;
+            a.buf_size = rate * 15 / 1000; a.n_rx = nl;
+            a.ceiling = 0.7 * QK_CLIP32;                                         // Agc1 max_out, quisk.c:2181
+            a.time_release = 1.0 - exp(-1.0 / rate / e->agc_release_time);       // quisk.c:2045
+            a.release_gain = e->d_release_gain; a.mode = e->d_mode; a.state = e->d_agc;
+            a.out = e->d_out; a.out_stride = (long long)e->out_stride; a.rx_list = c.d_members;
+            a.started = e->d_agc_started;
+            Timer tm(e, QK_KT_AGC);
+            hipLaunchKernelGGL(k_agc_gain, dim3((nl + 63) / 64), dim3(64), 0, e->stream, a);
+            hipLaunchKernelGGL(k_agc_apply, grid1(m, 1, nl), dim3(256), 0, e->stream, a);
+        }
+        for (int r : c.members) e->out_count[r] = m;
+    }
+    // ---- carry stream tails ----
+    {
+        TailArgs ta{}; ta.count = 0; ta.rx_list = nullptr;
+        add_tails(ta, F);
+        if (ta.count) hipLaunchKernelGGL(k_save_tails, dim3(ta.count, 2, e->nrx), dim3(256), 0, e->stream, ta);
+        for (int cl = 0; cl < CL_COUNT; cl++) {
+            Chain &c = e->cls_chain[cl];
+            const int nl = (int)c.members.size();
+            if (!nl) continue;
+            TailArgs tb{}; tb.count = 0; tb.rx_list = c.d_members;
+            add_tails(tb, c);
+            if (tb.count) hipLaunchKernelGGL(k_save_tails, dim3(tb.count, 2, nl), dim3(256), 0, e->stream, tb);
+            if (c.n_out > 0) {
+                // A receiver's first process_agc call returns the block untouched and does NOT store it in the
+                // delay ring (quisk.c:2033-2050): the ring (= the play stream's history) stays zero.
+                Stream &play = c.streams[c.play];
+                for (int r : c.members) {
+                    if (e->agc_started[r]) continue;
+                    hipMemsetAsync(play.d + (long long)r * play.rx_stride(), 0, sizeof(double) * play.hist, e->stream);
+                    hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_agc_started + r), 1, 1, e->stream);
+                    e->agc_started[r] = 1;
+                }
+            }
+        }
+    }
+    if (e->timing) hipEventRecord(ev_b1, e->stream);
+    HIPCHECK(hipGetLastError());
+    e->stats.samples_in += n;
+    e->stats.blocks += 1;
+    if (e->timing) {
+        HIPCHECK(hipStreamSynchronize(e->stream));
+        float ms = 0;
+        hipEventElapsedTime(&ms, ev_b0, ev_b1);
+        e->stats.last_block_ms = ms;
+        for (int b = 0; b < 8; b++) {
+            e->stats.last_kernel_ms[b] = 0;
+            if (e->ev_used[b]) { hipEventElapsedTime(&ms, e->ev[2 * b], e->ev[2 * b + 1]); e->stats.last_kernel_ms[b] = ms; }
+        }
+    }
+    return QK_OK;
+}
+
+// =================================================================================== C ABI
+extern "C" {
+
+const char *qk_last_error(void) { return g_err.c_str(); }
+const char *qk_version(void) { return "quisk_amd 0.1 (gfx950)"; }
+
+int qk_create(qk_engine **out, const qk_config *cfg)
+{
+    if (!out || !cfg) return fail(QK_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->sample_rate < 41000 || cfg->n_receivers < 1 || cfg->max_block < 1)
+        return fail(QK_EINVAL, "bad sample_rate / n_receivers / max_block");
+    const int pr = cfg->playback_rate / 48000;
+    if (cfg->playback_rate % 48000 || (pr != 1 && pr != 2 && pr != 4 && pr != 8))
+        return fail(QK_EINVAL, "playback_rate must be 48000 x {1,2,4,8} (quisk.c:2535-2553)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(QK_EHIP, "no HIP device: the engine has no CPU path");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(QK_EINVAL, "bad device ordinal");
+    qk_engine *e = new (std::nothrow) qk_engine();
+    if (!e) return fail(QK_ENOMEM, "out of host memory");
+    e->cfg = *cfg;
+    if (cfg->reserved[0] > 0) e->tap_cap = (cfg->reserved[0] + 1) & ~1;   // max receive-filter taps
+    int rc = engine_init(e);
+    if (rc != QK_OK) { std::string keep = g_err; qk_destroy(e); g_err = keep; return rc; }
+    *out = e;
+    return QK_OK;
+}
+
+void qk_destroy(qk_engine *e)
+{
+    if (!e) return;
+    hipSetDevice(e->cfg.device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    free_chain(e->front);
+    for (auto &c : e->cls_chain) free_chain(c);
+    for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
+    void *ptrs[] = {e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps,
+                    e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_out};
+    for (void *p : ptrs) if (p) hipFree(p);
+    for (auto &ev : e->ev) if (ev) hipEventDestroy(ev);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+#define ENGINE_ENTER(e)                                                  \
+    if (!(e)) return fail(QK_EINVAL, "null engine");                     \
+    std::lock_guard<std::mutex> _lk((e)->mu);                            \
+    HIPCHECK(hipSetDevice((e)->cfg.device))
+#define RX_CHECK(e, rx) if ((rx) < 0 || (rx) >= (e)->nrx) return fail(QK_ERANGE, "receiver index out of range")
+
+int qk_set_tune(qk_engine *e, int rx, int tune_hz)
+{
+    ENGINE_ENTER(e); RX_CHECK(e, rx);
+    if (e->tune[rx] == tune_hz) return QK_OK;
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    e->tune[rx] = tune_hz;
+    return upload_tune(e, rx);
+}
+
+int qk_set_mode(qk_engine *e, int rx, int mode)
+{
+    ENGINE_ENTER(e); RX_CHECK(e, rx);
+    const int cl = class_of_mode(mode);
+    if (cl < 0) return fail(QK_EUNSUPPORTED, "mode needs an external codec or is not on the GPU path yet");
+    if (e->mode[rx] == mode) return QK_OK;
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    e->mode[rx] = mode;
+    HIPCHECK(hipMemcpy(e->d_mode + rx, &mode, sizeof(int), hipMemcpyHostToDevice));
+    if (e->cls[rx] != cl) { e->cls[rx] = cl; return upload_members(e); }
+    return QK_OK;
+}
+
+int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int n, int bandwidth, int start_offset)
+{
+    ENGINE_ENTER(e); RX_CHECK(e, rx);
+    if (n < 0 || (n > 0 && (!fi || !fq))) return fail(QK_EINVAL, "bad filter arguments");
+    if (n >= 10001) return fail(QK_ERANGE, "Filter size must be less than 10001");       // quisk.c:4216-4219
+    if (n > e->tap_cap)
+        return fail(QK_ERANGE, "filter longer than the engine's tap capacity (qk_config.reserved[0])");
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    if (n > 0) {
+        HIPCHECK(hipMemcpy(e->d_taps + (size_t)rx * 2 * e->tap_cap, fi, sizeof(double) * n, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(e->d_taps + (size_t)rx * 2 * e->tap_cap + e->tap_cap, fq, sizeof(double) * n, hipMemcpyHostToDevice));
+    }
+    HIPCHECK(hipMemcpy(e->d_ntaps + rx, &n, sizeof(int), hipMemcpyHostToDevice));
+    e->ntaps[rx] = n; e->bandwidth[rx] = bandwidth; e->start_offset[rx] = start_offset;
+    return QK_OK;
+}
+
+int qk_set_agc(qk_engine *e, int rx, double release_gain)
+{
+    ENGINE_ENTER(e); RX_CHECK(e, rx);
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    HIPCHECK(hipMemcpy(e->d_release_gain + rx, &release_gain, sizeof(double), hipMemcpyHostToDevice));
+    return QK_OK;
+}
+
+int qk_set_agc_release_time(qk_engine *e, double seconds)
+{
+    ENGINE_ENTER(e);
+    if (!(seconds > 0)) return fail(QK_EINVAL, "release time must be positive");
+    e->agc_release_time = seconds;
+    return QK_OK;
+}
+
+int qk_process_samples_device(qk_engine *e, const double *iq_dev, int n)
+{
+    ENGINE_ENTER(e);
+    if (!iq_dev && n > 0) return fail(QK_EINVAL, "null sample pointer");
+    return process_device(e, reinterpret_cast<const double2 *>(iq_dev), n);
+}
+
+int qk_process_samples(qk_engine *e, const double *iq_host, int n)
+{
+    ENGINE_ENTER(e);
+    if (n < 0 || n > e->cfg.max_block) return fail(QK_ERANGE, "block larger than max_block");
+    if (!iq_host && n > 0) return fail(QK_EINVAL, "null sample pointer");
+    if (n > 0) {
+        HIPCHECK(hipStreamSynchronize(e->stream));      // the previous block may still read d_in
+        HIPCHECK(hipMemcpyAsync(e->d_in, iq_host, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, e->stream));
+    }
+    return process_device(e, e->d_in, n);
+}
+
+int qk_process_samples_int(qk_engine *e, const void *raw, size_t n_bytes, int bytes, int big_endian)
+{
+    ENGINE_ENTER(e);
+    if (bytes < 1 || bytes > 4) return fail(QK_EINVAL, "rx_bytes must be 1..4");
+    if (n_bytes % (size_t)(2 * bytes)) return fail(QK_EINVAL, "Odd number of bytes in sample buffer");   // quisk.c:2798
+    const size_t n = n_bytes / (2 * bytes);
+    if (n > (size_t)e->cfg.max_block) return fail(QK_ERANGE, "buffer is too full");                       // quisk.c:2801
+    if (n == 0) return process_device(e, e->d_in, 0);
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    if (n_bytes > e->raw_cap) {
+        if (e->d_raw) hipFree(e->d_raw);
+        e->raw_cap = (size_t)e->cfg.max_block * 8;
+        HIPCHECK(hipMalloc(&e->d_raw, e->raw_cap));
+    }
+    HIPCHECK(hipMemcpyAsync(e->d_raw, raw, n_bytes, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_unpack_int, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->d_raw, e->d_in, (int)n,
+                       bytes, big_endian);
+    return process_device(e, e->d_in, (int)n);
+}
+
+int qk_sync(qk_engine *e)
+{
+    ENGINE_ENTER(e);
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return QK_OK;
+}
+
+int qk_audio_count(qk_engine *e, int rx)
+{
+    ENGINE_ENTER(e); RX_CHECK(e, rx);
+    return e->out_count[rx];
+}
+
+int qk_pull_audio(qk_engine *e, int rx, double *dst, int cap)
+{
+    ENGINE_ENTER(e); RX_CHECK(e, rx);
+    const int m = std::min(e->out_count[rx], cap);
+    if (m > 0) {
+        if (!dst) return fail(QK_EINVAL, "null destination");
+        HIPCHECK(hipMemcpyAsync(dst, e->d_out + (size_t)rx * e->out_stride, (size_t)m * sizeof(double2),
+                                hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return m;
+}
+
+int qk_pull_audio_all(qk_engine *e, double *dst, size_t stride, int *counts)
+{
+    ENGINE_ENTER(e);
+    if (!dst || !counts) return fail(QK_EINVAL, "null destination");
+    for (int r = 0; r < e->nrx; r++) {
+        const int m = e->out_count[r];
+        if ((size_t)m > stride) return fail(QK_ERANGE, "stride smaller than the audio block");
+        counts[r] = m;
+    }
+    HIPCHECK(hipMemcpy2DAsync(dst, stride * sizeof(double2), e->d_out, e->out_stride * sizeof(double2),
+                              std::min(stride, e->out_stride) * sizeof(double2), e->nrx, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return QK_OK;
+}
+
+int qk_audio_device(qk_engine *e, const double **dev_ptr, size_t *stride)
+{
+    ENGINE_ENTER(e);
+    if (dev_ptr) *dev_ptr = reinterpret_cast<const double *>(e->d_out);
+    if (stride) *stride = e->out_stride;
+    return QK_OK;
+}
+
+int qk_get_graph(qk_engine *e, double zoom, double deltaf, double *out, int data_width, double *smeter)
+{
+    ENGINE_ENTER(e);
+    (void)zoom; (void)deltaf; (void)out; (void)data_width; (void)smeter;
+    if (e->cfg.fft_size <= 0) return fail(QK_EINVAL, "engine created without a display FFT");
+    return fail(QK_EUNSUPPORTED, "display FFT not implemented yet");
+}
+int qk_graph_pending(qk_engine *e) { ENGINE_ENTER(e); return 0; }
+int qk_graph_device(qk_engine *e, const double **dev_ptr) { ENGINE_ENTER(e); if (dev_ptr) *dev_ptr = nullptr; return QK_OK; }
+
+int qk_get_filter_rate(int sample_rate, int mode, int bandwidth) { return filter_rate(sample_rate, mode, bandwidth); }
+int qk_plan_decimation(int sample_rate, int *d2, int *d3, int *d5) { return plan_decimation(sample_rate, d2, d3, d5); }
+int qk_decim_rate(int sample_rate) { return decim_rate(sample_rate); }
+
+int qk_get_stats(qk_engine *e, qk_stats *out)
+{
+    ENGINE_ENTER(e);
+    if (!out) return fail(QK_EINVAL, "null argument");
+    *out = e->stats;
+    return QK_OK;
+}
+
+int qk_set_timing(qk_engine *e, int on) { ENGINE_ENTER(e); e->timing = on != 0; return QK_OK; }
+
+int qk_debug_tap(qk_engine *e, int which, int rx, double *out, int cap)
+{
+    ENGINE_ENTER(e); RX_CHECK(e, rx);
+    const Stream *s = nullptr;
+    Chain &c = e->cls_chain[e->cls[rx]];
+    switch (which) {
+    case QK_TAP_FRONTEND: s = &e->front.streams[0]; break;
+    case QK_TAP_DECIM: s = &e->front.streams[e->front.aud]; break;
+    case QK_TAP_DEMOD:
+        for (auto &st : c.stages) if (st.kind == ST_RXF) s = &c.streams[st.out];
+        break;
+    case QK_TAP_AUDIO48: if (c.built) s = &c.streams[c.aud]; break;
+    case QK_TAP_PLAY: if (c.built) s = &c.streams[c.play]; break;
+    }
+    if (!s || !s->d) return fail(QK_EINVAL, "no such tap");
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    const int m = std::min(s->n, cap);
+    for (int p = 0; p < s->planes && m > 0; p++)
+        HIPCHECK(hipMemcpy(out + (size_t)p * cap, s->d + (long long)rx * s->rx_stride() + (long long)p * (s->hist + s->cap) + s->hist,
+                           sizeof(double) * m, hipMemcpyDeviceToHost));
+    return m;
+}
+
+int quisk_cCplxSampleFilter(double *, int, const double *, int, int, double *, int *)
+{ return fail(QK_EUNSUPPORTED, "not implemented yet"); }
+int quisk_ccfFilter(double *, int, const double *, int, int, double *, int *)
+{ return fail(QK_EUNSUPPORTED, "not implemented yet"); }
+
+}  // extern "C"

@@ -1,0 +1,592 @@
+// qk_kernels.h -- gfx950 device code of the receive-DSP engine.
+//
+// Data layout in HBM ("streams"): every stage of the chain writes a PLANAR stream
+//     double d[receiver][plane][hist + cap]
+// plane 0 = real part, plane 1 = imaginary part (real-valued audio streams have one plane).  New samples of
+// a block start at offset `hist`; the `hist` doubles in front of them hold the tail of the previous
+// block, so a consumer reads x[i - k] for k up to its tap count with plain negative offsets and no
+// ring arithmetic.  All the FIRs of the reference have REAL coefficients (filter.c), so a complex
+// stream is two independent real streams and is processed plane by plane.
+//
+// Every kernel cites the reference lines whose arithmetic it reproduces.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define QK_CLIP32 2147483647.0
+
+struct StreamView {            // passed by value to kernels
+    double *d;
+    long long rx_stride;       // doubles between receivers
+    int plane_stride;          // doubles between planes (= hist + cap)
+    int hist;
+};
+__device__ __forceinline__ double *sv_ptr(const StreamView &s, int rx, int plane)
+{
+    return s.d + (long long)rx * s.rx_stride + (long long)plane * s.plane_stride + s.hist;
+}
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b)
+{
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// The 12 half-band constants (filter.c:359-362).
+#define HB_C0 0.000018566625444266
+#define HB_C1 -0.000118469698701817
+#define HB_C2 0.000457318798253456
+#define HB_C3 -0.001347840471412094
+#define HB_C4 0.003321838571445455
+#define HB_C5 -0.007198422696929033
+#define HB_C6 0.014211106939802483
+#define HB_C7 -0.026424776824073383
+#define HB_C8 0.048414810444971007
+#define HB_C9 -0.096214669073304823
+#define HB_C10 0.314881034738348550
+#define HB_C11 0.500000000000000000
+__device__ __constant__ double c_hb45[12] = { HB_C0, HB_C1, HB_C2, HB_C3, HB_C4, HB_C5, HB_C6, HB_C7, HB_C8,
+                                              HB_C9, HB_C10, HB_C11 };
+
+// ------------------------------------------------------------------------------------------------
+// Tune mixer (quisk.c:2350-2361).  The reference's running vector after k samples of this block is
+// v0 * phase^k; phase^k = A[k>>12] B[(k>>6)&63] C[k&63] with correctly rounded table entries made by the
+// host (qk_phasor.c), so the systematic drift of the never-renormalised recurrence is reproduced.
+// ------------------------------------------------------------------------------------------------
+struct MixTables {
+    const double2 *tabA, *tabB, *tabC;   // [rx][nA], [rx][64], [rx][64]
+    const double2 *v0;                   // [rx] vector at the first sample of this block
+    const int *mix_on;                   // [rx] 0 when tune == 0: the reference skips the multiply
+    int nA;
+};
+__device__ __forceinline__ double2 mix_base(const MixTables &m, int rx, long long j)   // j = k >> 6
+{
+    double2 t = cmul(m.v0[rx], m.tabA[(long long)rx * m.nA + (j >> 6)]);
+    return cmul(t, m.tabB[rx * 64 + (int)(j & 63)]);
+}
+__device__ __forceinline__ double2 mix_w(const MixTables &m, int rx, long long k)
+{
+    return cmul(mix_base(m, rx, k >> 6), m.tabC[rx * 64 + (int)(k & 63)]);
+}
+
+struct FrontArgs {
+    const double2 *x;          // this block's input, n interleaved complex samples
+    int n;
+    long long N0;              // global index of x[0] (samples consumed before this block)
+    const double2 *hist;       // [rx][H] mixed samples of global indices [N0-H, N0)
+    int H;
+    MixTables mt;
+    StreamView out;            // stage-S output stream (2 planes)
+    long long J0;              // global index of the first stage-S output of this block
+    long long g_lo0, g_end;    // global input range [g_lo0, g_end) consumed by this block's outputs (multiples of 2^S)
+    int span_len;              // input samples per workgroup (multiple of 2^S)
+};
+
+// Mixer alone (no half-band in front of the FIR chain: rates < 96 ksps).
+__global__ __launch_bounds__(256) void k_mix_only(FrontArgs a)
+{
+    const int rx = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    double2 v = a.x[i];
+    if (a.mt.mix_on[rx]) v = cmul(v, mix_w(a.mt, rx, i));
+    sv_ptr(a.out, rx, 0)[i] = v.x;
+    sv_ptr(a.out, rx, 1)[i] = v.y;
+}
+
+// After a block: the last H mixed samples become the next block's history, and the tune vector moves on
+// by phase^n.  hist_in/hist_out and v0/v0_next are ping-pong pairs.
+__global__ __launch_bounds__(256) void k_mixhist_update(FrontArgs a, double2 *hist_out, double2 *v0_next)
+{
+    const int rx = blockIdx.y;
+    const int on = a.mt.mix_on[rx];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.H; i += gridDim.x * 256) {
+        long long k = (long long)a.n - a.H + i;           // block-relative index
+        double2 v;
+        if (k >= 0) {
+            v = a.x[k];
+            if (on) v = cmul(v, mix_w(a.mt, rx, k));
+        } else {
+            v = a.hist[(long long)rx * a.H + i + a.n];
+        }
+        hist_out[(long long)rx * a.H + i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        v0_next[rx] = on ? mix_w(a.mt, rx, a.n) : a.mt.v0[rx];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Front end: mixer + S cascaded 45-tap half-band decimators (quisk_cDecim2HB45, filter.c:354-394),
+// fused.  One workgroup = one receiver x one span of the input.  The span is walked in chunks of CHUNK
+// samples; every level keeps its samples in LDS as two polyphase arrays per plane:
+//     E[j] = x[2j]   (feeds the centre tap:  center[] in the reference)
+//     O[j] = x[2j+1] (feeds the symmetric taps: samples[] in the reference)
+// so output m = sum_k c[k] (O[m-k] + O[m-21+k]) + c[11] E[m-10] is a contiguous dot product, and each
+// lane computes R = 6 consecutive outputs from 28 + 6 LDS doubles read as 16-byte vectors
+// (lane stride 48 B: conflict-free for ds_read_b128).  22 samples of history per array carry the filter
+// state from chunk to chunk; a span warms its histories up by running 44*2^S input samples ahead of its
+// first output (those come from the previous block's mixed-history buffer at a block start).
+// Global index convention: stage-s output j is emitted at input index 2^s j + 2^s - 1 (the reference
+// emits on every second input, toggle starting at 0).
+// ------------------------------------------------------------------------------------------------
+#define FE_THREADS 256
+#define FE_R 6
+#define FE_HIST 22
+
+template <int CHUNK> struct FeLayout {
+    // level s: 4 sub-arrays (plane*2 + phase), each SUB(s) doubles; O arrays start one double late so that
+    // index m0+1 (m0 multiple of 6) is 16-byte aligned, E arrays read from m0+12 (even).
+    static __host__ __device__ constexpr int sub(int s) { return (CHUNK >> (s + 1)) + FE_HIST + 12; }
+    static __host__ __device__ constexpr int level_off(int s) { int o = 0; for (int i = 0; i < s; i++) o += 4 * sub(i); return o; }
+    static __host__ __device__ constexpr int total(int S) { return level_off(S) + 2 * (CHUNK / 64 + 2) + 128; }
+};
+
+template <int CHUNK>
+__device__ __forceinline__ double *fe_arr(double *smem, int s, int plane, int phase)
+{
+    // phase 1 (O) is shifted by one double for alignment of the vector reads
+    return smem + FeLayout<CHUNK>::level_off(s) + (plane * 2 + phase) * FeLayout<CHUNK>::sub(s) + phase;
+}
+
+// R consecutive outputs m0..m0+R-1 of one half-band stage from the polyphase arrays of its input level.
+__device__ __forceinline__ void hb45_block(const double *__restrict__ O, const double *__restrict__ E, int m0,
+                                           double (&y)[FE_R])
+{
+    double o[FE_R + 22];
+    double e[FE_R];
+    const double2 *po = reinterpret_cast<const double2 *>(O + m0 + 1);      // O index of x[2(m0)+1 - 42] ...
+#pragma unroll
+    for (int j = 0; j < (FE_R + 22) / 2; j++) { double2 v = po[j]; o[2 * j] = v.x; o[2 * j + 1] = v.y; }
+    const double2 *pe = reinterpret_cast<const double2 *>(E + m0 + 12);
+#pragma unroll
+    for (int j = 0; j < FE_R / 2; j++) { double2 v = pe[j]; e[2 * j] = v.x; e[2 * j + 1] = v.y; }
+#pragma unroll
+    for (int r = 0; r < FE_R; r++) {
+        // samples[k] = o[r+21-k]; pair k with 21-k, in the reference's order k = 0..10, then the centre tap
+        double acc = (o[r + 21] + o[r]) * HB_C0;
+        acc = fma(o[r + 20] + o[r + 1], HB_C1, acc);
+        acc = fma(o[r + 19] + o[r + 2], HB_C2, acc);
+        acc = fma(o[r + 18] + o[r + 3], HB_C3, acc);
+        acc = fma(o[r + 17] + o[r + 4], HB_C4, acc);
+        acc = fma(o[r + 16] + o[r + 5], HB_C5, acc);
+        acc = fma(o[r + 15] + o[r + 6], HB_C6, acc);
+        acc = fma(o[r + 14] + o[r + 7], HB_C7, acc);
+        acc = fma(o[r + 13] + o[r + 8], HB_C8, acc);
+        acc = fma(o[r + 12] + o[r + 9], HB_C9, acc);
+        acc = fma(o[r + 11] + o[r + 10], HB_C10, acc);
+        y[r] = fma(e[r], HB_C11, acc);
+    }
+}
+
+template <int S, int CHUNK>
+__global__ __launch_bounds__(FE_THREADS) void k_frontend(FrontArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    using LY = FeLayout<CHUNK>;
+    const int rx = blockIdx.y, t = threadIdx.x;
+    const long long g_lo = a.g_lo0 + (long long)blockIdx.x * a.span_len;
+    if (g_lo >= a.g_end) return;
+    const long long g_hi = (g_lo + a.span_len < a.g_end) ? g_lo + a.span_len : a.g_end;
+    constexpr int W = 44 << S;
+    double2 *sbase = reinterpret_cast<double2 *>(smem + LY::level_off(S));
+    double2 *sC = sbase + (CHUNK / 64 + 2);
+
+    for (int i = t; i < LY::level_off(S); i += FE_THREADS) smem[i] = 0.0;
+    const int mix = a.mt.mix_on[rx];
+    if (t < 64) sC[t] = a.mt.tabC[rx * 64 + t];
+    const double2 *histp = a.hist + (long long)rx * a.H;
+    double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
+
+    long long pos = g_lo - W;
+    while (pos < g_hi) {
+        const bool emit = pos >= g_lo;
+        const long long lim = emit ? g_hi : g_lo;
+        const int c = (lim - pos < CHUNK) ? (int)(lim - pos) : CHUNK;      // multiple of 2^S
+        const long long k0 = pos - a.N0;                                    // block-relative index of the chunk start
+        const long long jb = k0 >> 6;
+        __syncthreads();                                                    // previous chunk done with sbase / arrays
+        if (mix && t < c / 64 + 2) {
+            long long j = jb + t;
+            if (j >= 0) sbase[t] = mix_base(a.mt, rx, j);
+        }
+        __syncthreads();
+        // ---- load + mix into level 0 ----
+        {
+            double *E0 = fe_arr<CHUNK>(smem, 0, 0, 0), *O0 = fe_arr<CHUNK>(smem, 0, 0, 1);
+            double *E1 = fe_arr<CHUNK>(smem, 0, 1, 0), *O1 = fe_arr<CHUNK>(smem, 0, 1, 1);
+            for (int i = t; i < c; i += FE_THREADS) {
+                const long long k = k0 + i;
+                double2 v;
+                if (k >= 0) {
+                    v = a.x[k];
+                    if (mix) v = cmul(v, cmul(sbase[(int)((k >> 6) - jb)], sC[(int)(k & 63)]));
+                } else {
+                    const long long hi = k + a.H;
+                    v = hi >= 0 ? histp[hi] : make_double2(0.0, 0.0);
+                }
+                const int idx = FE_HIST + (i >> 1);
+                if (i & 1) { O0[idx] = v.x; O1[idx] = v.y; } else { E0[idx] = v.x; E1[idx] = v.y; }
+            }
+        }
+        __syncthreads();
+        // ---- S half-band stages ----
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const int n_out = c >> (s + 1);
+            const int ipp = (n_out + FE_R - 1) / FE_R;                      // work items per plane
+            for (int w = t; w < 2 * ipp; w += FE_THREADS) {
+                const int plane = w >= ipp;
+                const int q = plane ? w - ipp : w;
+                const int m0 = q * FE_R;
+                double y[FE_R];
+                hb45_block(fe_arr<CHUNK>(smem, s, plane, 1), fe_arr<CHUNK>(smem, s, plane, 0), m0, y);
+                if (s + 1 < S) {
+                    double *En = fe_arr<CHUNK>(smem, s + 1, plane, 0), *On = fe_arr<CHUNK>(smem, s + 1, plane, 1);
+#pragma unroll
+                    for (int r = 0; r < FE_R; r++) {
+                        const int m = m0 + r;
+                        if (m < n_out) {
+                            if (m & 1) On[FE_HIST + (m >> 1)] = y[r]; else En[FE_HIST + (m >> 1)] = y[r];
+                        }
+                    }
+                } else if (emit) {
+                    double *op = (plane ? out1 : out0) + ((pos >> S) - a.J0);
+#pragma unroll
+                    for (int r = 0; r < FE_R; r++)
+                        if (m0 + r < n_out) op[m0 + r] = y[r];
+                }
+            }
+            __syncthreads();
+        }
+        // ---- carry the last 22 entries of every polyphase array to its front ----
+        {
+            double keep[2];
+            int cnt = 0;
+            for (int w = t; w < S * 4 * FE_HIST; w += FE_THREADS, cnt++) {
+                const int s = w / (4 * FE_HIST), rem = w % (4 * FE_HIST);
+                const int sub = rem / FE_HIST, i = rem % FE_HIST;
+                keep[cnt] = fe_arr<CHUNK>(smem, s, sub >> 1, sub & 1)[(c >> (s + 1)) + i];
+            }
+            __syncthreads();
+            cnt = 0;
+            for (int w = t; w < S * 4 * FE_HIST; w += FE_THREADS, cnt++) {
+                const int s = w / (4 * FE_HIST), rem = w % (4 * FE_HIST);
+                const int sub = rem / FE_HIST, i = rem % FE_HIST;
+                fe_arr<CHUNK>(smem, s, sub >> 1, sub & 1)[i] = keep[cnt];
+            }
+        }
+        pos += c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic real-coefficient FIR with decimation on a planar stream: quisk_cDecimate / quisk_dDecimate /
+// quisk_dFilter / quisk_cFilter (filter.c:180-206, 236-262, 324-352).  Output j uses the newest input at
+// index first + D j and accumulates h[k] x[newest - k] for k = 0..T-1 in the reference's order.
+// grid (ceil(n_out/256), planes, receivers); the taps are wave-uniform (scalar loads).
+// ------------------------------------------------------------------------------------------------
+struct FirArgs {
+    StreamView in, out;
+    const double *h; int T, D, first, n_out;
+    const int *rx_list;        // receivers to process (nullptr = blockIdx.z is the receiver)
+    long long h_rx_stride;     // taps per receiver (0 = shared table)
+};
+
+__global__ __launch_bounds__(256) void k_fir_decim(FirArgs a)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.n_out) return;
+    const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
+    const int plane = blockIdx.y;
+    const double *__restrict__ p = sv_ptr(a.in, rx, plane) + a.first + (long long)a.D * j;
+    const double *__restrict__ h = a.h + a.h_rx_stride * rx;
+    double acc = 0.0;
+    for (int k = 0; k < a.T; k++) acc = fma(p[-k], h[k], acc);
+    sv_ptr(a.out, rx, plane)[j] = acc;
+}
+
+// Polyphase interpolator x L (quisk_dInterpolate / quisk_cInterpolate, filter.c:108-178):
+// out[L i + jj] = L * sum_{k < T/L} h[jj + k L] x[i - k].
+struct InterpArgs { StreamView in, out; const double *h; int T, L, n_in; const int *rx_list; };
+__global__ __launch_bounds__(256) void k_interp(InterpArgs a)
+{
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= a.n_in * a.L) return;
+    const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
+    const int plane = blockIdx.y;
+    const int i = o / a.L, jj = o - i * a.L;
+    const double *__restrict__ p = sv_ptr(a.in, rx, plane) + i;
+    double acc = 0.0;
+    const int terms = a.T / a.L;
+    for (int k = 0; k < terms; k++) acc = fma(p[-k], a.h[jj + k * a.L], acc);
+    sv_ptr(a.out, rx, plane)[o] = acc * a.L;
+}
+
+// Rational resampler x L / D (quisk_cInterpDecim, filter.c:264-301): output m sits at virtual position
+// v = idx0 + m D of the L-times upsampled stream: input i = v / L, polyphase branch v % L.
+struct ResampArgs { StreamView in, out; const double *h; int T, L, D, idx0, n_out; const int *rx_list; };
+__global__ __launch_bounds__(256) void k_resample(ResampArgs a)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= a.n_out) return;
+    const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
+    const int plane = blockIdx.y;
+    const long long v = a.idx0 + (long long)m * a.D;
+    const int i = (int)(v / a.L), ph = (int)(v - (long long)i * a.L);
+    const double *__restrict__ p = sv_ptr(a.in, rx, plane) + i;
+    double acc = 0.0;
+    const int terms = a.T / a.L;
+    for (int k = 0; k < terms; k++) acc = fma(p[-k], a.h[ph + k * a.L], acc);
+    sv_ptr(a.out, rx, plane)[m] = acc * a.L;
+}
+
+// Half-band interpolator x 2 (quisk_dInterp2HB45 / quisk_cInterp2HB45, filter.c:397-465):
+// out[2i] = x[i-11] c[11] 2;  out[2i+1] = 2 sum_{k<11} (x[i-k] + x[i-21+k]) c[k].
+struct HbInterpArgs { StreamView in, out; int n_in; const int *rx_list; };
+__global__ __launch_bounds__(256) void k_hb_interp(HbInterpArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n_in) return;
+    const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
+    const int plane = blockIdx.y;
+    const double *__restrict__ p = sv_ptr(a.in, rx, plane) + i;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 11; k++) acc = fma(p[-k] + p[-21 + k], c_hb45[k], acc);
+    double *o = sv_ptr(a.out, rx, plane) + 2 * (long long)i;
+    o[0] = p[-11] * HB_C11 * 2;
+    o[1] = acc * 2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Receive band-pass + detector.
+//   cRxFilterOut (quisk.c:1154-1192): I taps on the real plane, Q taps on the imaginary plane.
+//   dRxFilterOut (quisk.c:1118-1152): I taps on both planes.
+// Tap order quirk of both: the newest sample meets tap 0, then tap k (k >= 1) meets x[n - (N - k)].
+// N == 0 passes the sample through (quisk.c:1137, 1174).
+// mode_kind: 0 = SSB/CW/DGT (audio = re -/+ im, quisk.c:1786,1805,1823,1847), 1 = AM magnitude (cabs,
+// quisk.c:1868), 2 = FM: keep the filtered complex sample (2 planes out).
+// ------------------------------------------------------------------------------------------------
+struct RxfArgs {
+    StreamView in, out;
+    const double *taps;        // [rx][2][tap_cap]  (I taps, Q taps)
+    const int *ntaps;          // [rx]
+    const int *mode;           // [rx] rx_mode_type
+    int tap_cap, n, kind;
+    const int *rx_list;
+};
+__global__ __launch_bounds__(256) void k_rxfilter(RxfArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
+    const int N = a.ntaps[rx];
+    const double *__restrict__ pr = sv_ptr(a.in, rx, 0) + i;
+    const double *__restrict__ pi = sv_ptr(a.in, rx, 1) + i;
+    const double *__restrict__ fi = a.taps + (long long)rx * 2 * a.tap_cap;
+    const double *__restrict__ fq = (a.kind == 0) ? fi + a.tap_cap : fi;
+    double ar, ai;
+    if (N == 0) {
+        ar = pr[0]; ai = pi[0];
+    } else {
+        ar = pr[0] * fi[0]; ai = pi[0] * fq[0];
+        for (int k = 1; k < N; k++) {
+            ar = fma(pr[k - N], fi[k], ar);
+            ai = fma(pi[k - N], fq[k], ai);
+        }
+    }
+    if (a.kind == 0) {
+        const int m = a.mode[rx];
+        const bool lower = (m == 0 /*CWL*/ || m == 2 /*LSB*/ || m == 8 /*DGT_L*/);
+        sv_ptr(a.out, rx, 0)[i] = lower ? ar + ai : ar - ai;
+    } else if (a.kind == 1) {
+        sv_ptr(a.out, rx, 0)[i] = hypot(ar, ai);
+    } else {
+        sv_ptr(a.out, rx, 0)[i] = ar;
+        sv_ptr(a.out, rx, 1)[i] = ai;
+    }
+}
+
+// FM discriminator (quisk.c:1894-1896): d = fs * arg(c[i] conj(c[i-1])); c[-1] of the very first block is 10.
+struct FmDiscArgs { StreamView in, out; int n; double fs; const int *rx_list; };
+__global__ __launch_bounds__(256) void k_fm_disc(FmDiscArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
+    const double *pr = sv_ptr(a.in, rx, 0) + i, *pi = sv_ptr(a.in, rx, 1) + i;
+    const double cr = pr[0], ci = pi[0], qr = pr[-1], qi = pi[-1];
+    const double re = cr * qr + ci * qi;       // c * conj(q)
+    const double im = ci * qr - cr * qi;
+    sv_ptr(a.out, rx, 0)[i] = a.fs * atan2(im, re);
+}
+
+// Serial one-pole recurrences, one lane per receiver.
+//   kind 0: AM DC removal (quisk.c:1869-1871): d = m + 0.99 dc; y = d - dc; dc = d.
+//   kind 1: FM de-emphasis (quisk.c:1898-1900): y = x a0 + x1 a1 - y1 b1.
+struct IirArgs { StreamView in, out; int n, kind; double a0, a1, b1; double *state; const int *rx_list; int n_rx; };
+__global__ __launch_bounds__(64) void k_serial_iir(IirArgs a)
+{
+#pragma clang fp contract(off)      // recurrences: keep the reference's separately rounded products and sums
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= a.n_rx) return;
+    const int rx = a.rx_list ? a.rx_list[li] : li;
+    const double *__restrict__ p = sv_ptr(a.in, rx, 0);
+    double *__restrict__ o = sv_ptr(a.out, rx, 0);
+    double s0 = a.state[2 * rx], s1 = a.state[2 * rx + 1];
+    if (a.kind == 0) {
+        for (int i = 0; i < a.n; i++) {
+            const double d = p[i] + s0 * 0.99;
+            o[i] = d - s0;
+            s0 = d;
+        }
+    } else {
+        for (int i = 0; i < a.n; i++) {     // s0 = x1, s1 = y1
+            const double x = p[i];
+            const double y = x * a.a0 + s0 * a.a1 - s1 * a.b1;
+            o[i] = y;
+            s0 = x; s1 = y;
+        }
+    }
+    a.state[2 * rx] = s0; a.state[2 * rx + 1] = s1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AGC (process_agc, quisk.c:2022-2147), mono path (is_cpx == 0, quisk.c:2573-2575).
+// The look-ahead ring of the reference is the stream's own history: the delayed sample is x[i - buf_size].
+// Pass 1 (serial per receiver) walks the gain state machine and records the gain applied at each sample;
+// pass 2 (parallel) applies it and the hard limiter.
+// ------------------------------------------------------------------------------------------------
+struct AgcState {
+    double themax, gain, delta, target_gain;
+    int index_read, index_start, is_clipping, pad;
+};
+struct AgcArgs {
+    StreamView in;             // mono audio at the play rate, hist >= buf_size
+    double *gains;             // [rx][cap]
+    int gain_stride, n, buf_size, n_rx;
+    double ceiling;            // max_out * CLIP32
+    double time_release;
+    const double *release_gain;   // [rx] agcReleaseGain
+    const int *mode;           // [rx]
+    AgcState *state;           // [rx]
+    double2 *out; long long out_stride;   // [rx][out_stride] interleaved stereo
+    const int *rx_list;
+    const int *started;        // [rx] 0 until the receiver's first call: the reference then only initialises
+                               // and returns the block untouched (quisk.c:2033-2050)
+};
+__global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
+{
+    // No FMA contraction: the state machine ends a gain ramp on `gain <= target` after exactly buf_size
+    // subtractions of (gain - target) / buf_size (quisk.c:2120-2121), an equality decided by the last bit.
+    // With separately rounded operations this kernel is bit-identical to the reference's arithmetic on
+    // identical input.
+#pragma clang fp contract(off)
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= a.n_rx) return;
+    const int rx = a.rx_list ? a.rx_list[li] : li;
+    if (!a.started[rx]) return;
+    const double *__restrict__ p = sv_ptr(a.in, rx, 0);
+    double *__restrict__ g = a.gains + (long long)rx * a.gain_stride;
+    AgcState s = a.state[rx];
+    const double rel = a.release_gain[rx], tr = a.time_release, ceil_ = a.ceiling;
+    const int md = a.mode[rx];
+    const bool fm = (md == 5 || md == 13);
+    const double bs = (double)a.buf_size;
+    for (int i = 0; i < a.n; i++) {
+        g[i] = s.gain;
+        const double m = fabs(p[i]);
+        if (!s.is_clipping) {
+            if (m * s.gain > ceil_) {
+                s.target_gain = ceil_ / m;
+                s.delta = (s.gain - s.target_gain) / bs;
+                s.is_clipping = 1;
+                s.themax = m;
+                s.gain -= s.delta;
+            } else if (s.index_read == s.index_start) {
+                const double clip_gain = ceil_ / s.themax;
+                s.target_gain = fm ? clip_gain : (rel > clip_gain ? clip_gain : rel);
+                s.themax = m;
+                s.gain = s.gain * (1.0 - tr) + s.target_gain * tr;
+            } else {
+                if (s.themax < m) s.themax = m;
+                s.gain = s.gain * (1.0 - tr) + s.target_gain * tr;
+            }
+        } else {
+            if (m > s.themax) {
+                s.themax = m;
+                s.target_gain = ceil_ / m;
+                const double d = (s.gain - s.target_gain) / bs;
+                if (d > s.delta) s.delta = d;
+            }
+            s.gain -= s.delta;
+            if (s.gain <= s.target_gain) {
+                s.is_clipping = 0;
+                s.gain = s.target_gain;
+                s.themax = m;
+                s.index_start = s.index_read;
+            }
+        }
+        if (++s.index_read >= a.buf_size) s.index_read = 0;
+    }
+    a.state[rx] = s;
+}
+__global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
+    const double *p = sv_ptr(a.in, rx, 0) + i;
+    double d;
+    if (!a.started[rx]) {
+        d = p[0];
+    } else {
+        d = p[-a.buf_size] * a.gains[(long long)rx * a.gain_stride + i];
+        const double m = fabs(d);
+        if (m > QK_CLIP32) d = d / m;      // sic: the reference divides by the magnitude (quisk.c:2065)
+    }
+    a.out[(long long)rx * a.out_stride + i] = make_double2(d, d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// End of block: move the last `hist` samples of every stream to the front of its buffer.
+// ------------------------------------------------------------------------------------------------
+#define QK_MAX_TAILS 24
+struct TailDesc { double *d; long long rx_stride; int plane_stride, planes, hist, n; };
+struct TailArgs { TailDesc t[QK_MAX_TAILS]; int count; const int *rx_list; };
+__global__ __launch_bounds__(256) void k_save_tails(TailArgs a)
+{
+    // grid (count, 2 planes, receivers)
+    const TailDesc td = a.t[blockIdx.x];
+    if ((int)blockIdx.y >= td.planes || td.n <= 0) return;
+    const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
+    double *base = td.d + (long long)rx * td.rx_stride + (long long)blockIdx.y * td.plane_stride;
+    // dest[i] = src[i + n], i in [0, hist); ascending chunks keep reads ahead of writes when n < hist
+    for (int c0 = 0; c0 < td.hist; c0 += 256) {
+        const int i = c0 + threadIdx.x;
+        double v = 0.0;
+        if (i < td.hist) v = base[i + td.n];
+        __syncthreads();
+        if (i < td.hist) base[i] = v;
+        __syncthreads();
+    }
+}
+
+// add_rx_samples (quisk.c:2804-2834): signed integers of `bytes` bytes, left-justified into int32.
+__global__ __launch_bounds__(256) void k_unpack_int(const unsigned char *raw, double2 *out, int n, int bytes, int big_endian)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char *p = raw + (size_t)i * 2 * bytes;
+    int32_t v[2];
+    for (int c = 0; c < 2; c++) {
+        uint32_t u = 0;
+        for (int b = 0; b < bytes; b++) {
+            const uint32_t byte = p[c * bytes + b];
+            const int sig = big_endian ? (bytes - 1 - b) : b;       // significance of this byte within the sample
+            u |= byte << (8 * (4 - bytes + sig));
+        }
+        v[c] = (int32_t)u;
+    }
+    out[i] = make_double2((double)v[0], (double)v[1]);
+}

@@ -1,0 +1,207 @@
+"""ctypes mirror of include/qk_engine.h.  Loads quisk_amd/libqkengine.so and fails loudly if it is missing:
+there is no CPU path in this package."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqkengine.so")
+
+
+class QkError(RuntimeError):
+    pass
+
+
+class QkConfig(C.Structure):
+    _fields_ = [("device", C.c_int), ("sample_rate", C.c_int), ("playback_rate", C.c_int),
+                ("n_receivers", C.c_int), ("max_block", C.c_int), ("fft_size", C.c_int),
+                ("data_width", C.c_int), ("reserved", C.c_int * 8)]
+
+
+class QkStats(C.Structure):
+    _fields_ = [("samples_in", C.c_int64), ("blocks", C.c_int64), ("fft_frames", C.c_int64),
+                ("fft_error", C.c_int64), ("last_block_ms", C.c_double), ("last_kernel_ms", C.c_double * 8)]
+
+
+KT_FRONTEND, KT_DECIM, KT_DEMOD, KT_AUDIO, KT_AGC, KT_FFT = range(6)
+TAP_FRONTEND, TAP_DECIM, TAP_DEMOD, TAP_AUDIO48, TAP_PLAY = range(5)
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QkError("%s is missing: build it with `make` or __graft_entry__.build()" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+    L.qk_last_error.restype = C.c_char_p
+    L.qk_version.restype = C.c_char_p
+    L.qk_create.argtypes = [C.POINTER(vp), C.POINTER(QkConfig)]
+    L.qk_destroy.argtypes = [vp]
+    L.qk_destroy.restype = None
+    L.qk_set_tune.argtypes = [vp, C.c_int, C.c_int]
+    L.qk_set_mode.argtypes = [vp, C.c_int, C.c_int]
+    L.qk_set_filters.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int]
+    L.qk_set_agc.argtypes = [vp, C.c_int, C.c_double]
+    L.qk_set_agc_release_time.argtypes = [vp, C.c_double]
+    L.qk_process_samples.argtypes = [vp, vp, C.c_int]
+    L.qk_process_samples_device.argtypes = [vp, vp, C.c_int]
+    L.qk_process_samples_int.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int]
+    L.qk_sync.argtypes = [vp]
+    L.qk_audio_count.argtypes = [vp, C.c_int]
+    L.qk_pull_audio.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.qk_pull_audio_all.argtypes = [vp, vp, C.c_size_t, ip]
+    L.qk_audio_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.qk_get_graph.argtypes = [vp, C.c_double, C.c_double, vp, C.c_int, dp]
+    L.qk_graph_pending.argtypes = [vp]
+    L.qk_graph_device.argtypes = [vp, C.POINTER(vp)]
+    L.qk_get_filter_rate.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.qk_plan_decimation.argtypes = [C.c_int, ip, ip, ip]
+    L.qk_decim_rate.argtypes = [C.c_int]
+    L.qk_get_stats.argtypes = [vp, C.POINTER(QkStats)]
+    L.qk_set_timing.argtypes = [vp, C.c_int]
+    L.qk_debug_tap.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    L.quisk_cCplxSampleFilter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip]
+    L.quisk_ccfFilter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise QkError("qk error %d: %s" % (rc, lib().qk_last_error().decode()))
+    return rc
+
+
+def plan_decimation(rate):
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    best = lib().qk_plan_decimation(rate, C.byref(a), C.byref(b), C.byref(c))
+    return best, a.value, b.value, c.value
+
+
+def get_filter_rate(rate, mode, bw):
+    return lib().qk_get_filter_rate(rate, mode, bw)
+
+
+def decim_rate(rate):
+    return lib().qk_decim_rate(rate)
+
+
+class Engine:
+    """N receivers on one wideband I/Q stream (the reference's quisk_process_samples, batched)."""
+
+    def __init__(self, sample_rate, n_receivers=1, playback_rate=48000, max_block=66000, fft_size=0,
+                 data_width=0, device=0, max_filter_taps=0):
+        self.L = lib()
+        cfg = QkConfig(device=device, sample_rate=sample_rate, playback_rate=playback_rate,
+                       n_receivers=n_receivers, max_block=max_block, fft_size=fft_size, data_width=data_width)
+        cfg.reserved[0] = max_filter_taps
+        self.h = C.c_void_p()
+        _check(self.L.qk_create(C.byref(self.h), C.byref(cfg)))
+        self.n_receivers = n_receivers
+        self.sample_rate = sample_rate
+        self.playback_rate = playback_rate
+        self.max_block = max_block
+        self.data_width = data_width
+        self.out_cap = int(max_block * playback_rate // sample_rate + 256)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.qk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setters (names of the reference's Python entry points) ----
+    def set_tune(self, rx, hz):
+        _check(self.L.qk_set_tune(self.h, rx, int(hz)))
+
+    def set_mode(self, rx, mode):
+        _check(self.L.qk_set_mode(self.h, rx, int(mode)))
+
+    def set_filters(self, rx, filt_i, filt_q, bandwidth, start_offset):
+        fi = np.ascontiguousarray(filt_i, dtype=np.float64)
+        fq = np.ascontiguousarray(filt_q, dtype=np.float64)
+        if len(fi) != len(fq):
+            raise QkError("The size of filters I and Q must be equal")      # quisk.c:4212-4215
+        _check(self.L.qk_set_filters(self.h, rx, fi.ctypes.data, fq.ctypes.data, len(fi), int(bandwidth), int(start_offset)))
+
+    def set_agc(self, rx, gain):
+        _check(self.L.qk_set_agc(self.h, rx, float(gain)))
+
+    def set_agc_release_time(self, seconds):
+        _check(self.L.qk_set_agc_release_time(self.h, float(seconds)))
+
+    def set_timing(self, on):
+        _check(self.L.qk_set_timing(self.h, int(bool(on))))
+
+    # ---- data path ----
+    def process(self, iq):
+        """One block of complex128 samples in host memory."""
+        x = np.ascontiguousarray(iq, dtype=np.complex128)
+        _check(self.L.qk_process_samples(self.h, x.ctypes.data, len(x)))
+
+    def process_device(self, dev_ptr, n):
+        """One block already resident in device memory (dev_ptr: integer address of n complex doubles)."""
+        _check(self.L.qk_process_samples_device(self.h, C.c_void_p(int(dev_ptr)), int(n)))
+
+    def process_int(self, raw, nbytes_per_component, big_endian=False):
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        _check(self.L.qk_process_samples_int(self.h, buf.ctypes.data, buf.size, nbytes_per_component, int(big_endian)))
+
+    def sync(self):
+        _check(self.L.qk_sync(self.h))
+
+    def audio(self, rx):
+        out = np.empty(self.out_cap, dtype=np.complex128)
+        m = _check(self.L.qk_pull_audio(self.h, rx, out.ctypes.data, self.out_cap))
+        return out[:m].copy()
+
+    def audio_all(self):
+        out = np.empty((self.n_receivers, self.out_cap), dtype=np.complex128)
+        counts = (C.c_int * self.n_receivers)()
+        _check(self.L.qk_pull_audio_all(self.h, out.ctypes.data, self.out_cap, counts))
+        return out, np.array(counts[:], dtype=np.int64)
+
+    def audio_device(self):
+        p, s = C.c_void_p(), C.c_size_t()
+        _check(self.L.qk_audio_device(self.h, C.byref(p), C.byref(s)))
+        return p.value, s.value
+
+    def process_stream(self, iq, block, rx=None):
+        """Feed `iq` in blocks; returns the concatenated audio of receiver rx (or a list for all)."""
+        outs = [[] for _ in range(self.n_receivers)]
+        which = range(self.n_receivers) if rx is None else [rx]
+        for i in range(0, len(iq), block):
+            self.process(iq[i:i + block])
+            for r in which:
+                outs[r].append(self.audio(r))
+        cat = [np.concatenate(o) if o else np.zeros(0, np.complex128) for o in outs]
+        return cat if rx is None else cat[rx]
+
+    def get_graph(self, zoom=1.0, deltaf=0.0):
+        """(count, dB row, smeter); count == 0 means no data, like get_graph returning None."""
+        out = np.empty(max(self.data_width, 1), dtype=np.float64)
+        sm = C.c_double(0.0)
+        n = _check(self.L.qk_get_graph(self.h, float(zoom), float(deltaf), out.ctypes.data, self.data_width, C.byref(sm)))
+        return n, out, sm.value
+
+    def stats(self):
+        st = QkStats()
+        _check(self.L.qk_get_stats(self.h, C.byref(st)))
+        return st
+
+    def tap(self, which, rx, planes=2, cap=None):
+        cap = cap or (self.max_block + 64)
+        out = np.zeros((planes, cap), dtype=np.float64)
+        m = _check(self.L.qk_debug_tap(self.h, which, rx, out.ctypes.data, cap))
+        return out[:, :m].copy()

@@ -94,6 +94,8 @@ def oracle():
     L.qko_rx_set_filter.argtypes = [C.c_void_p, ddp, ddp, C.c_int, C.c_int]
     L.qko_rx_set_agc.argtypes = [C.c_void_p, C.c_double, C.c_double]
     L.qko_rx_process.argtypes = [C.c_void_p, cdp, C.c_int]
+    L.qko_rx_pre_agc.argtypes = [C.c_void_p, cdp, C.c_int]
+    L.qko_rx_agc.argtypes = [C.c_void_p, cdp, C.c_int]
     L.qko_rx_mix.argtypes = [C.c_void_p, cdp, C.c_int]
     L.qko_rx_decimate.argtypes = [C.c_void_p, cdp, C.c_int]
     L.qko_rx_demodulate.argtypes = [C.c_void_p, cdp, ddp, C.c_int]
@@ -146,10 +148,20 @@ class OracleRx:
         """x: complex128 block (<= 66000); returns the stereo audio block."""
         buf = np.array(x, dtype=np.complex128, copy=True)
         cap = max(len(buf), 16)
-        work = np.zeros(max(cap, 2 * cap), dtype=np.complex128)
+        work = np.zeros(9 * cap + 64, dtype=np.complex128)
         work[:len(buf)] = buf
         m = self.L.qko_rx_process(self.h, work, len(buf))
         return work[:m].copy()
+
+    def process_parts(self, x):
+        """(pre-AGC stereo block at the play rate, final block)"""
+        n = len(x)
+        work = np.zeros(9 * n + 64, dtype=np.complex128)
+        work[:n] = x
+        m = self.L.qko_rx_pre_agc(self.h, work, n)
+        pre = work[:m].copy()
+        self.L.qko_rx_agc(self.h, work, m)
+        return pre, work[:m].copy()
 
     def process_stream(self, x, block):
         outs = [self.process(x[i:i + block]) for i in range(0, len(x), block)]

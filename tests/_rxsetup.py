@@ -1,0 +1,124 @@
+"""Shared set-up for the parity tests: configure an oracle receiver and an engine receiver identically,
+and compare them block by block.
+
+Parity contract ("Parity"):
+  1. everything in front of the AGC (mixer, decimators, band-pass, detector, audio interpolators): the
+     engine's AGC input matches the oracle's within TOL = 1e-9 of the block peak (BASELINE.json north_star);
+  2. the AGC kernels are BIT-EXACT against the oracle's process_agc restatement when both are fed the same
+     samples (the engine's own AGC input): stronger than 1e-9;
+  3. end to end through the AGC the tolerance is TOL_AGC = 1e-6.  process_agc is ill-conditioned by
+     construction: it ends a gain ramp on `gain <= target_gain` after subtracting (gain-target)/buf_size
+     exactly buf_size times (quisk.c:2079, 2120-2121), an equality decided by the last bit, so inputs that
+     differ by one ulp can end the ramp one sample apart and shift the following release window
+     (tests/test_oracle_rx.py::test_agc_is_ill_conditioned shows it on the oracle alone).
+"""
+import ctypes as C
+
+import numpy as np
+
+import _bind as B
+from quisk_amd import rxfilters
+from quisk_amd.engine import TAP_PLAY
+from quisk_amd.synth import DEFAULT_BW
+
+TOL = 1e-9
+TOL_AGC = 1e-6
+
+
+def rx_filter(sample_rate, mode, bw=None):
+    """(fi, fq, bw, start_offset) as quisk.py OnBtnFilter builds them (quisk.py:4837-4868)."""
+    name = rxfilters.MODES[mode]
+    bw = bw or DEFAULT_BW[mode]
+    frate = B.oracle().qko_get_filter_rate(sample_rate, mode, bw)
+    bw = min(bw, frate // 2)
+    center = rxfilters.filter_center(name, bw)
+    fi, fq = rxfilters.make_filter_coef(frate, None, bw, center)
+    return fi, fq, bw, center - bw // 2
+
+
+def make_oracle_rx(sample_rate, mode, tune, playback_rate=48000, agc_gain=80.0):
+    fi, fq, bw, _ = rx_filter(sample_rate, mode)
+    return B.OracleRx(sample_rate, playback_rate, mode=mode, tune=int(tune), fi=fi, fq=fq, bandwidth=bw, agc_gain=agc_gain)
+
+
+def configure_engine(eng, modes, tunes, agc_gain=80.0):
+    for r, (m, t) in enumerate(zip(modes, tunes)):
+        fi, fq, bw, off = rx_filter(eng.sample_rate, int(m))
+        eng.set_mode(r, int(m))
+        eng.set_tune(r, int(t))
+        eng.set_filters(r, fi, fq, bw, off)
+        eng.set_agc(r, agc_gain)
+
+
+def rel_err(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size == 0:
+        return 0.0
+    scale = np.max(np.abs(b))
+    return float(np.max(np.abs(a - b)) / (scale if scale > 0 else 1.0))
+
+
+class AgcTwin:
+    """The oracle's process_agc run on the ENGINE's own AGC input, to check the AGC kernels bit for bit."""
+
+    def __init__(self, playback_rate, mode, agc_gain=80.0):
+        self.L = B.oracle()
+        self.st = B.OAgc()
+        self.L.qko_agc_init(C.byref(self.st), 0.7, 0)
+        self.rate, self.gain, self.fm = playback_rate, agc_gain, int(mode in (5, 13))
+
+    def run(self, mono):
+        s = (mono + 1j * mono).astype(np.complex128)
+        if len(s):
+            self.L.qko_agc_process(C.byref(self.st), s, len(s), 0, self.rate, self.gain, 1.0, self.fm)
+        return s
+
+
+class PairRunner:
+    """Engine and per-receiver oracles stepped together; accumulates the three parity measures."""
+
+    def __init__(self, eng, modes, tunes, agc_gain=80.0, pre_tol=None):
+        self.eng = eng
+        self.modes = [int(m) for m in modes]
+        configure_engine(eng, modes, tunes, agc_gain)
+        self.oras = [make_oracle_rx(eng.sample_rate, int(m), int(t), eng.playback_rate, agc_gain) for m, t in zip(modes, tunes)]
+        self.twins = [AgcTwin(eng.playback_rate, int(m), agc_gain) for m in modes]
+        self.pre_err = 0.0
+        self.agc_exact = True
+        self.final_err = 0.0
+        self.samples = 0
+        self.peak = [0.0] * len(self.oras)
+        self.pre_tol = pre_tol
+
+    def step(self, blk):
+        self.eng.process(blk)
+        for r, o in enumerate(self.oras):
+            pre_o, fin_o = o.process_parts(blk)
+            fin_g = self.eng.audio(r)
+            pre_g = self.eng.tap(TAP_PLAY, r, planes=1)[0]
+            assert len(fin_g) == len(fin_o) == len(pre_g), (len(fin_g), len(fin_o), len(pre_g))
+            if not len(fin_o):
+                continue
+            self.samples += len(fin_o)
+            # errors are taken relative to the receiver's running audio peak, so that an almost silent
+            # start-up block is not judged against its own tiny amplitude
+            self.peak[r] = max(self.peak[r], float(np.max(np.abs(pre_o.real))))
+            scale = self.peak[r] if self.peak[r] > 0 else 1.0
+            self.pre_err = max(self.pre_err, float(np.max(np.abs(pre_g - pre_o.real))) / scale)
+            twin = self.twins[r].run(pre_g)
+            if not np.array_equal(twin.view(np.float64), fin_g.view(np.float64)):
+                self.agc_exact = False
+            fscale = max(float(np.max(np.abs(fin_o))), 1.0)
+            self.final_err = max(self.final_err, float(np.max(np.abs(fin_g - fin_o))) / fscale)
+
+    def close(self):
+        for o in self.oras:
+            o.close()
+        self.eng.close()
+
+    def check(self, pre_tol=TOL, final_tol=TOL_AGC):
+        assert self.samples > 0
+        assert self.pre_err < (self.pre_tol or pre_tol), "pre-AGC error %g" % self.pre_err
+        assert self.agc_exact, "AGC kernels are not bit-exact against the oracle on identical input"
+        assert self.final_err < final_tol, "end-to-end error %g" % self.final_err

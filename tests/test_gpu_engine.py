@@ -1,0 +1,99 @@
+"""HIP engine (through the C ABI) against the CPU oracle on identical seeded I/Q.  The parity contract and
+its tolerances are stated in tests/_rxsetup.py."""
+import numpy as np
+import pytest
+
+import _bind as B
+from _rxsetup import PairRunner, TOL, configure_engine, make_oracle_rx, rel_err
+from quisk_amd import Engine
+from quisk_amd.engine import TAP_DECIM
+from quisk_amd.synth import make_iq, tune_offsets, mode_mix
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream(fs, modes, tunes, sizes, seed, playback=48000, max_block=None, pre_tol=None):
+    x = make_iq(sum(sizes), fs, tunes, modes, seed)
+    eng = Engine(fs, n_receivers=len(modes), playback_rate=playback, max_block=max_block or max(sizes))
+    pr = PairRunner(eng, modes, tunes, pre_tol=pre_tol)
+    pos = 0
+    for s in sizes:
+        pr.step(x[pos:pos + s])
+        pos += s
+    pr.close()
+    return pr
+
+
+def test_c1_192k_usb_single_receiver():
+    """BASELINE config 1: 192 ksps, one USB receiver, 960-sample blocks (5 ms poll)."""
+    fs = 192000
+    pr = _stream(fs, [3], [int(0.1 * fs)], [960] * 100, 1001)
+    assert pr.samples == 100 * 240
+    pr.check()
+
+
+def test_frontend_and_decimation_taps_1536k():
+    """Mixer + 4 fused half-bands + FIR98/2 against the oracle's mixer and quisk_process_decimate restatement."""
+    fs, n, block = 1536000, 3 * 16384 + 1000, 16384
+    tunes = tune_offsets(4, fs)
+    modes = mode_mix(4)
+    x = make_iq(n, fs, tunes, modes, 1002)
+    eng = Engine(fs, n_receivers=4, max_block=block)
+    configure_engine(eng, modes, tunes)
+    L = B.oracle()
+    rxs = [make_oracle_rx(fs, 3, int(t)) for t in tunes]
+    for i in range(0, n, block):
+        blk = x[i:i + block]
+        eng.process(blk)
+        for r, o in enumerate(rxs):
+            w = np.concatenate([blk, np.zeros(8, complex)])
+            L.qko_rx_mix(o.h, w, len(blk))
+            m = L.qko_rx_decimate(o.h, w, len(blk))
+            dec = eng.tap(TAP_DECIM, r)
+            assert dec.shape[1] == m
+            assert rel_err(dec[0] + 1j * dec[1], w[:m]) < TOL
+    eng.close()
+
+
+def test_c2_1536k_ssb_receivers_ragged_blocks():
+    """BASELINE config 2 at reduced length: USB and LSB receivers on a 1.536 Msps stream; ragged block sizes
+    including tiny and odd ones (the carried state must not depend on the block size)."""
+    fs = 1536000
+    tunes = tune_offsets(6, fs)
+    modes = np.array([3, 2, 3, 2, 3, 3])
+    pr = _stream(fs, modes, tunes, [65536, 1000, 33333, 7, 65536, 40001], 1002)
+    pr.check()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])
+def test_modes_192k(mode):
+    """CWL, CWU, LSB, USB, AM, FM end to end at 192 ksps."""
+    pr = _stream(192000, [mode], [25000], [9600] * 15, 77 + mode)
+    assert pr.samples == 15 * 2400
+    pr.check()
+
+
+@pytest.mark.parametrize("playback", [96000, 192000])
+def test_playback_interpolation(playback):
+    """Interpolation to a 96 / 192 ksps play rate (quisk.c:2535-2553); the AGC then runs at that rate."""
+    pr = _stream(192000, [3], [-31000], [4800] * 12, 5, playback=playback)
+    pr.check()
+
+
+def test_mixed_modes_retune_midstream():
+    """Mixed SSB/AM/FM receivers; receiver 1 is retuned between blocks (the phasor is not reset, quisk.c:2168)."""
+    fs = 1536000
+    nrx = 4
+    tunes = list(tune_offsets(nrx, fs))
+    modes = mode_mix(nrx, "mixed")
+    block = 32768
+    x = make_iq(block * 6, fs, tunes, modes, 1004)
+    eng = Engine(fs, n_receivers=nrx, max_block=block)
+    pr = PairRunner(eng, modes, tunes)
+    for i in range(6):
+        if i == 3:
+            eng.set_tune(1, int(tunes[1]) + 1234)
+            pr.oras[1].set_tune(int(tunes[1]) + 1234)
+        pr.step(x[i * block:(i + 1) * block])
+    pr.close()
+    pr.check()
