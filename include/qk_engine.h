@@ -86,6 +86,9 @@ int qk_pull_audio_all(qk_engine *e, double *dst_host, size_t stride, int *counts
 /* Device pointer and stride (in complex samples) of the audio output array, for zero-copy consumers
  * and for the RCCL gather. */
 int qk_audio_device(qk_engine *e, const double **dev_ptr, size_t *stride);
+/* Device-to-device copy of the last block's audio into a caller-owned device buffer
+ * [n_receivers][dst_stride] complex samples (e.g. the send buffer of an RCCL gather). */
+int qk_export_audio_device(qk_engine *e, double *dst_dev, size_t dst_stride);
 
 /* get_graph (quisk.c:4602-4759) with the wall-clock gate (quisk.c:4712) left to the caller: returns the
  * number of FFT frames averaged since the last release (0 = no data, `out` untouched), writes
@@ -108,13 +111,19 @@ typedef struct qk_stats {
     int64_t blocks;            /* calls to qk_process_* */
     int64_t fft_frames;        /* display FFT frames transformed */
     int64_t fft_error;         /* frames dropped (fft_error, quisk.c:38); always 0: the GPU path never drops */
-    double last_block_ms;      /* device time of the last block (HIP events), or 0 when timing is off */
-    double last_kernel_ms[8];  /* device time of the named kernels of the last block: see QK_KT_* */
+    /* HIP-event timing on the engine's stream (only while qk_set_timing is on): */
+    double last_block_ms;      /* device time of the last timed block */
+    double block_ms_sum;       /* sum over timed blocks */
+    int64_t blocks_timed;
+    double kernel_ms_sum[8];   /* per kernel group QK_KT_*: sum of launch durations */
+    int64_t kernel_launches[8];
 } qk_stats;
 enum { QK_KT_FRONTEND = 0, QK_KT_DECIM = 1, QK_KT_DEMOD = 2, QK_KT_AUDIO = 3, QK_KT_AGC = 4, QK_KT_FFT = 5 };
 int qk_get_stats(qk_engine *e, qk_stats *out);
-/* Per-stage HIP-event timing (off by default: the events serialise nothing but cost a few us). */
+/* Per-launch HIP-event timing of the kernel groups (off by default).  Events are recorded on the engine's
+ * own stream and read back at qk_get_stats, so the timed region is not synchronised. */
 int qk_set_timing(qk_engine *e, int on);
+int qk_reset_stats(qk_engine *e);
 
 /* Stage taps for parity tests (debug): copy the planar output of an internal stream to the host.
  * which: QK_TAP_*; out: [planes][count] doubles; returns count per plane. */

@@ -33,6 +33,7 @@ namespace {
 
 constexpr int FE_CHUNK = 1536;
 constexpr int DEFAULT_TAP_CAP = 1024;
+constexpr int EV_POOL = 2048;
 
 enum StageKind { ST_FIR, ST_INTERP, ST_HBINT, ST_RESAMP, ST_RXF, ST_FMDISC, ST_IIR, ST_FRAC };
 enum ChainClass { CL_SSB = 0, CL_CW, CL_AM, CL_FM, CL_COUNT };
@@ -112,8 +113,12 @@ struct qk_engine {
     // stats / timing
     qk_stats stats{};
     bool timing = false;
-    hipEvent_t ev[16]{};
-    bool ev_used[16]{};
+    // HIP-event timing: pairs are recorded on the engine's stream around the timed launches and read
+    // back lazily (at qk_get_stats or when the pool runs out), so timing adds no host synchronisation
+    std::vector<hipEvent_t> ev_pool;
+    struct EvPair { int bucket; int e0, e1; };
+    std::vector<EvPair> ev_pending;
+    int ev_next = 0;
 };
 
 namespace {
@@ -530,20 +535,43 @@ static int engine_init(qk_engine *e)
     if (rc != QK_OK) return rc;
     rc = upload_members(e);
     if (rc != QK_OK) return rc;
-    for (int i = 0; i < 16; i++) HIPCHECK(hipEventCreate(&e->ev[i]));
+    e->ev_pool.resize(EV_POOL);
+    for (auto &ev : e->ev_pool) HIPCHECK(hipEventCreate(&ev));
     HIPCHECK(hipDeviceSynchronize());
     return QK_OK;
 }
 
 // ---------------------------------------------------------------------------------- per-block work
 namespace {
-struct Timer {
-    qk_engine *e; int bucket; bool on;
-    Timer(qk_engine *en, int b) : e(en), bucket(b), on(en->timing && b >= 0 && b < 8)
-    {
-        if (on && !e->ev_used[bucket]) hipEventRecord(e->ev[2 * bucket], e->stream);   // first start ... last end
+int drain_events(qk_engine *e)
+{
+    if (e->ev_pending.empty()) { e->ev_next = 0; return QK_OK; }
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    for (auto &p : e->ev_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e->ev_pool[p.e0], e->ev_pool[p.e1]) != hipSuccess) continue;
+        if (p.bucket == 8) { e->stats.block_ms_sum += ms; e->stats.blocks_timed += 1; e->stats.last_block_ms = ms; }
+        else { e->stats.kernel_ms_sum[p.bucket] += ms; e->stats.kernel_launches[p.bucket] += 1; }
     }
-    ~Timer() { if (on) { hipEventRecord(e->ev[2 * bucket + 1], e->stream); e->ev_used[bucket] = true; } }
+    e->ev_pending.clear();
+    e->ev_next = 0;
+    return QK_OK;
+}
+struct Timer {      // bucket 0..7 = QK_KT_*, 8 = whole block
+    qk_engine *e; int bucket; int e0 = -1;
+    Timer(qk_engine *en, int b) : e(en), bucket(b)
+    {
+        if (!e->timing || b < 0 || b > 8) return;
+        if (e->ev_next + 2 > (int)e->ev_pool.size()) drain_events(e);
+        e0 = e->ev_next; e->ev_next += 2;
+        hipEventRecord(e->ev_pool[e0], e->stream);
+    }
+    ~Timer()
+    {
+        if (e0 < 0) return;
+        hipEventRecord(e->ev_pool[e0 + 1], e->stream);
+        e->ev_pending.push_back({bucket, e0, e0 + 1});
+    }
 };
 }  // namespace
 
@@ -654,9 +682,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
 {
     if (n < 0 || n > e->cfg.max_block) return fail(QK_ERANGE, "block larger than max_block");
     if (n == 0) { for (auto &c : e->out_count) c = 0; return QK_OK; }
-    for (int i = 0; i < 8; i++) e->ev_used[i] = false;
-    hipEvent_t ev_b0 = e->ev[14], ev_b1 = e->ev[15];
-    if (e->timing) hipEventRecord(ev_b0, e->stream);
+    Timer block_timer(e, 8);
     const int S = e->S;
     Chain &F = e->front;
     // ---- front end ----
@@ -727,7 +753,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             a.out = e->d_out; a.out_stride = (long long)e->out_stride; a.rx_list = c.d_members;
             a.started = e->d_agc_started;
             Timer tm(e, QK_KT_AGC);
-            hipLaunchKernelGGL(k_agc_gain, dim3((nl + 63) / 64), dim3(64), 0, e->stream, a);
+            hipLaunchKernelGGL(k_agc_gain, dim3(nl), dim3(64), 0, e->stream, a);
             hipLaunchKernelGGL(k_agc_apply, grid1(m, 1, nl), dim3(256), 0, e->stream, a);
         }
         for (int r : c.members) e->out_count[r] = m;
@@ -757,20 +783,9 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             }
         }
     }
-    if (e->timing) hipEventRecord(ev_b1, e->stream);
     HIPCHECK(hipGetLastError());
     e->stats.samples_in += n;
     e->stats.blocks += 1;
-    if (e->timing) {
-        HIPCHECK(hipStreamSynchronize(e->stream));
-        float ms = 0;
-        hipEventElapsedTime(&ms, ev_b0, ev_b1);
-        e->stats.last_block_ms = ms;
-        for (int b = 0; b < 8; b++) {
-            e->stats.last_kernel_ms[b] = 0;
-            if (e->ev_used[b]) { hipEventElapsedTime(&ms, e->ev[2 * b], e->ev[2 * b + 1]); e->stats.last_kernel_ms[b] = ms; }
-        }
-    }
     return QK_OK;
 }
 
@@ -814,7 +829,7 @@ void qk_destroy(qk_engine *e)
     void *ptrs[] = {e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps,
                     e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_out};
     for (void *p : ptrs) if (p) hipFree(p);
-    for (auto &ev : e->ev) if (ev) hipEventDestroy(ev);
+    for (auto &ev : e->ev_pool) if (ev) hipEventDestroy(ev);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -986,11 +1001,41 @@ int qk_get_stats(qk_engine *e, qk_stats *out)
 {
     ENGINE_ENTER(e);
     if (!out) return fail(QK_EINVAL, "null argument");
+    int rc = drain_events(e);
+    if (rc != QK_OK) return rc;
     *out = e->stats;
     return QK_OK;
 }
 
-int qk_set_timing(qk_engine *e, int on) { ENGINE_ENTER(e); e->timing = on != 0; return QK_OK; }
+int qk_set_timing(qk_engine *e, int on)
+{
+    ENGINE_ENTER(e);
+    int rc = drain_events(e);
+    e->timing = on != 0;
+    return rc;
+}
+
+int qk_reset_stats(qk_engine *e)
+{
+    ENGINE_ENTER(e);
+    int rc = drain_events(e);
+    e->stats = qk_stats{};
+    return rc;
+}
+
+int qk_export_audio_device(qk_engine *e, double *dst_dev, size_t dst_stride)
+{
+    ENGINE_ENTER(e);
+    if (!dst_dev) return fail(QK_EINVAL, "null destination");
+    size_t w = 0;
+    for (int r = 0; r < e->nrx; r++) w = std::max(w, (size_t)e->out_count[r]);
+    if (w > dst_stride) return fail(QK_ERANGE, "stride smaller than the audio block");
+    if (w > 0)
+        HIPCHECK(hipMemcpy2DAsync(dst_dev, dst_stride * sizeof(double2), e->d_out, e->out_stride * sizeof(double2),
+                                  w * sizeof(double2), e->nrx, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return QK_OK;
+}
 
 int qk_debug_tap(qk_engine *e, int which, int rx, double *out, int cap)
 {

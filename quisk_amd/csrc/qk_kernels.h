@@ -474,61 +474,144 @@ struct AgcArgs {
     const int *started;        // [rx] 0 until the receiver's first call: the reference then only initialises
                                // and returns the block untouched (quisk.c:2033-2050)
 };
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// One sample of the reference's state machine, verbatim (quisk.c:2076-2131).
+struct AgcConst { double rel, tr, keep, ceil_, bs; int buf_size; bool fm; };
+__device__ __forceinline__ void agc_step(AgcState &s, const double m, const AgcConst &c)
+{
+#pragma clang fp contract(off)
+    if (!s.is_clipping) {
+        if (m * s.gain > c.ceil_) {
+            s.target_gain = c.ceil_ / m;
+            s.delta = (s.gain - s.target_gain) / c.bs;
+            s.is_clipping = 1;
+            s.themax = m;
+            s.gain -= s.delta;
+        } else if (s.index_read == s.index_start) {
+            const double clip_gain = c.ceil_ / s.themax;
+            s.target_gain = c.fm ? clip_gain : (c.rel > clip_gain ? clip_gain : c.rel);
+            s.themax = m;
+            s.gain = s.gain * c.keep + s.target_gain * c.tr;
+        } else {
+            if (s.themax < m) s.themax = m;
+            s.gain = s.gain * c.keep + s.target_gain * c.tr;
+        }
+    } else {
+        if (m > s.themax) {
+            s.themax = m;
+            s.target_gain = c.ceil_ / m;
+            const double d = (s.gain - s.target_gain) / c.bs;
+            if (d > s.delta) s.delta = d;
+        }
+        s.gain -= s.delta;
+        if (s.gain <= s.target_gain) {
+            s.is_clipping = 0;
+            s.gain = s.target_gain;
+            s.themax = m;
+            s.index_start = s.index_read;
+        }
+    }
+    if (++s.index_read >= c.buf_size) s.index_read = 0;
+}
+
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double w = __shfl_xor(v, o, 64);
+        v = v < w ? w : v;
+    }
+    return v;
+}
+
+// One WAVE per receiver.  The state machine is serial in time, but almost every sample takes one of two
+// trivial paths: "not clipping, no new clip, not at the window boundary" (gain = gain*(1-tr) + target*tr,
+// themax = max(themax, m)) or "clipping, no new maximum, ramp not finished" (gain -= delta).  The wave
+// therefore runs a tile of 64 samples SPECULATIVELY down the current path -- the serial part is only the
+// two-operation gain recurrence, whose value before each sample is dropped into that sample's lane -- and
+// then tests all 64 samples for an event (clip start, window boundary, new maximum, end of ramp) in one
+// lane-parallel pass.  Samples in front of the first event are committed, the event sample goes through
+// the full state machine (agc_step), and speculation restarts behind it.  Every floating-point operation
+// is the reference's own, in its order, without FMA contraction: the result is bit-identical to a
+// sample-by-sample walk (tests check it against the oracle).
 __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
 {
-    // No FMA contraction: the state machine ends a gain ramp on `gain <= target` after exactly buf_size
-    // subtractions of (gain - target) / buf_size (quisk.c:2120-2121), an equality decided by the last bit.
-    // With separately rounded operations this kernel is bit-identical to the reference's arithmetic on
-    // identical input.
 #pragma clang fp contract(off)
-    const int li = blockIdx.x * 64 + threadIdx.x;
-    if (li >= a.n_rx) return;
-    const int rx = a.rx_list ? a.rx_list[li] : li;
+    const int rx = a.rx_list ? a.rx_list[blockIdx.x] : blockIdx.x;
     if (!a.started[rx]) return;
+    const int lane = threadIdx.x;
     const double *__restrict__ p = sv_ptr(a.in, rx, 0);
     double *__restrict__ g = a.gains + (long long)rx * a.gain_stride;
     AgcState s = a.state[rx];
-    const double rel = a.release_gain[rx], tr = a.time_release, ceil_ = a.ceiling;
+    AgcConst c;
+    c.rel = a.release_gain[rx]; c.tr = a.time_release; c.keep = 1.0 - a.time_release; c.ceil_ = a.ceiling;
+    c.bs = (double)a.buf_size; c.buf_size = a.buf_size;
     const int md = a.mode[rx];
-    const bool fm = (md == 5 || md == 13);
-    const double bs = (double)a.buf_size;
-    for (int i = 0; i < a.n; i++) {
-        g[i] = s.gain;
-        const double m = fabs(p[i]);
-        if (!s.is_clipping) {
-            if (m * s.gain > ceil_) {
-                s.target_gain = ceil_ / m;
-                s.delta = (s.gain - s.target_gain) / bs;
-                s.is_clipping = 1;
-                s.themax = m;
-                s.gain -= s.delta;
-            } else if (s.index_read == s.index_start) {
-                const double clip_gain = ceil_ / s.themax;
-                s.target_gain = fm ? clip_gain : (rel > clip_gain ? clip_gain : rel);
-                s.themax = m;
-                s.gain = s.gain * (1.0 - tr) + s.target_gain * tr;
+    c.fm = (md == 5 || md == 13);
+    __shared__ double sg[72];         // gain in force at each sample of the tile, [64] = gain after the tile
+    double mv = (lane < a.n) ? fabs(p[lane]) : 0.0;
+    for (int i0 = 0; i0 < a.n; i0 += 64) {
+        const int nxt = i0 + 64 + lane;
+        const double mv_next = (nxt < a.n) ? fabs(p[nxt]) : 0.0;      // in flight while this tile is walked
+        const int cnt = (a.n - i0 < 64) ? a.n - i0 : 64;
+        double gv = 0.0;                                               // gain in force at this lane's sample
+        int start = 0;
+        while (start < cnt) {
+            double gcur = s.gain;
+            const bool mine = lane >= start && lane < cnt;
+            bool ev;
+            if (!s.is_clipping) {
+                const double tt = s.target_gain * c.tr;
+                if (lane == 0) {                                       // the serial part: 2 flops per sample
+                    double gc = gcur;
+#pragma unroll 8
+                    for (int j = start; j < cnt; j++) { sg[j] = gc; gc = gc * c.keep + tt; }
+                    sg[64] = gc;
+                }
+                if (lane >= start) gv = sg[lane];
+                gcur = sg[64];
+                int idx = s.index_read + (lane - start);               // buf_size >= 720 > 64: one wrap at most
+                if (idx >= a.buf_size) idx -= a.buf_size;
+                ev = mine && ((mv * gv > c.ceil_) || (idx == s.index_start));
             } else {
-                if (s.themax < m) s.themax = m;
-                s.gain = s.gain * (1.0 - tr) + s.target_gain * tr;
+                const double dl = s.delta;
+                if (lane == 0) {
+                    double gc = gcur;
+#pragma unroll 8
+                    for (int j = start; j < cnt; j++) { sg[j] = gc; gc = gc - dl; }
+                    sg[64] = gc;
+                }
+                if (lane >= start) gv = sg[lane];
+                gcur = sg[64];
+                ev = mine && ((mv > s.themax) || (gv - dl <= s.target_gain));
             }
-        } else {
-            if (m > s.themax) {
-                s.themax = m;
-                s.target_gain = ceil_ / m;
-                const double d = (s.gain - s.target_gain) / bs;
-                if (d > s.delta) s.delta = d;
+            const unsigned long long mask = __ballot(ev);
+            const int f = mask ? (int)__ffsll((long long)mask) - 1 : cnt;     // first event sample
+            if (!s.is_clipping) {
+                const double red = wave_max_f64((lane >= start && lane < f) ? mv : 0.0);
+                if (s.themax < red) s.themax = red;
             }
-            s.gain -= s.delta;
-            if (s.gain <= s.target_gain) {
-                s.is_clipping = 0;
-                s.gain = s.target_gain;
-                s.themax = m;
-                s.index_start = s.index_read;
+            s.index_read += f - start;
+            if (s.index_read >= a.buf_size) s.index_read -= a.buf_size;
+            if (f >= cnt) {
+                s.gain = gcur;
+                start = cnt;
+            } else {
+                s.gain = readlane_f64(gv, f);
+                agc_step(s, readlane_f64(mv, f), c);
+                start = f + 1;
             }
         }
-        if (++s.index_read >= a.buf_size) s.index_read = 0;
+        if (i0 + lane < a.n) g[i0 + lane] = gv;
+        mv = mv_next;
     }
-    a.state[rx] = s;
+    if (lane == 0) a.state[rx] = s;
 }
 __global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
 {

@@ -21,7 +21,8 @@ class QkConfig(C.Structure):
 
 class QkStats(C.Structure):
     _fields_ = [("samples_in", C.c_int64), ("blocks", C.c_int64), ("fft_frames", C.c_int64),
-                ("fft_error", C.c_int64), ("last_block_ms", C.c_double), ("last_kernel_ms", C.c_double * 8)]
+                ("fft_error", C.c_int64), ("last_block_ms", C.c_double), ("block_ms_sum", C.c_double),
+                ("blocks_timed", C.c_int64), ("kernel_ms_sum", C.c_double * 8), ("kernel_launches", C.c_int64 * 8)]
 
 
 KT_FRONTEND, KT_DECIM, KT_DEMOD, KT_AUDIO, KT_AGC, KT_FFT = range(6)
@@ -65,6 +66,8 @@ def lib():
     L.qk_decim_rate.argtypes = [C.c_int]
     L.qk_get_stats.argtypes = [vp, C.POINTER(QkStats)]
     L.qk_set_timing.argtypes = [vp, C.c_int]
+    L.qk_reset_stats.argtypes = [vp]
+    L.qk_export_audio_device.argtypes = [vp, vp, C.c_size_t]
     L.qk_debug_tap.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
     L.quisk_cCplxSampleFilter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip]
     L.quisk_ccfFilter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip]
@@ -194,6 +197,12 @@ class Engine:
         sm = C.c_double(0.0)
         n = _check(self.L.qk_get_graph(self.h, float(zoom), float(deltaf), out.ctypes.data, self.data_width, C.byref(sm)))
         return n, out, sm.value
+
+    def reset_stats(self):
+        _check(self.L.qk_reset_stats(self.h))
+
+    def export_audio_device(self, dst_dev_ptr, dst_stride):
+        _check(self.L.qk_export_audio_device(self.h, C.c_void_p(int(dst_dev_ptr)), int(dst_stride)))
 
     def stats(self):
         st = QkStats()
