@@ -35,11 +35,11 @@ typedef struct qk_config {
     int device;            /* HIP device ordinal */
     int sample_rate;       /* input I/Q rate, quisk_sound_state.sample_rate (record_app `rate`, quisk.c:5070) */
     int playback_rate;     /* audio rate: 48000 x {1,2,4,8} (quisk.c:2535-2553) */
-    int n_receivers;       /* number of independent receivers (reference: 3 banks) */
+    int n_receivers;       /* number of independent receivers (reference: 3 banks); 0 = spectrum only */
     int max_block;         /* largest n accepted by qk_process_* (reference: SAMP_BUFFER_SIZE 66000, quisk.h:15) */
     int fft_size;          /* display FFT size, power of two, or 0 for no spectrum (record_app, quisk.c:5054) */
     int data_width;        /* graph points returned by qk_get_graph (record_app, quisk.c:5054) */
-    int reserved[8];       /* must be zero */
+    int reserved[8];       /* [0] = largest receive-filter length accepted by qk_set_filters (0 = 1024); rest zero */
 } qk_config;
 
 /* record_app (quisk.c:5048-5113): allocates the FFT buffers/window and initialises every filter state
@@ -94,6 +94,8 @@ int qk_export_audio_device(qk_engine *e, double *dst_dev, size_t dst_stride);
  * number of FFT frames averaged since the last release (0 = no data, `out` untouched), writes
  * data_width dB values and the S-meter value (quisk.c:4728-4737), and clears the average. */
 int qk_get_graph(qk_engine *e, double zoom, double deltaf, double *out, int data_width, double *smeter);
+/* get_smeter (quisk.c:2737-2742): the value computed by the last qk_get_graph release. */
+double qk_get_smeter(qk_engine *e);
 /* Frames waiting in the average (count_fft, quisk.c:4613) without releasing them. */
 int qk_graph_pending(qk_engine *e);
 /* Device pointer to the last released graph row (data_width doubles), for the RCCL gather. */

@@ -4,6 +4,7 @@
 // include/qk_engine.h.  No CPU fallback: every entry point that computes needs a HIP device.
 #include "../../include/qk_engine.h"
 #include "qk_kernels.h"
+#include "qk_fft.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -110,6 +111,13 @@ struct qk_engine {
     // output
     double2 *d_out = nullptr; size_t out_stride = 0;
     std::vector<int> out_count;
+    // display spectrum (get_graph)
+    int fftN = 0, fftN1 = 1, fftW = 0, fft_fill = 0, fft_count = 0;
+    double2 *d_fft_stage = nullptr, *d_fft_Y = nullptr, *d_tw4096 = nullptr, *d_tw_lo = nullptr, *d_tw_hi = nullptr;
+    double *d_window = nullptr, *d_fft_avg = nullptr, *d_band = nullptr, *d_meter = nullptr, *d_graph = nullptr, *d_pix = nullptr;
+    int *d_k0 = nullptr;
+    int band_cap = 0;
+    double smeter = -160.0 + 4.25969;
     // stats / timing
     qk_stats stats{};
     bool timing = false;
@@ -450,32 +458,11 @@ static const double *push_table(DevTables &t, const double *src, int n)
     return reinterpret_cast<const double *>(off);      // offset, turned into a pointer after upload
 }
 
-static int engine_init(qk_engine *e)
+static int init_spectrum(qk_engine *e);
+
+static int init_receivers(qk_engine *e)
 {
     const qk_config &cfg = e->cfg;
-    HIPCHECK(hipSetDevice(cfg.device));
-    HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    e->nrx = cfg.n_receivers;
-    // coefficient tables
-    DevTables T;
-    double hb43[43] = {0};
-    static const double c12[12] = { HB_C0, HB_C1, HB_C2, HB_C3, HB_C4, HB_C5, HB_C6, HB_C7, HB_C8, HB_C9, HB_C10, HB_C11 };
-    for (int k = 0; k < 11; k++) { hb43[2 * k] = c12[k]; hb43[42 - 2 * k] = c12[k]; }
-    hb43[21] = c12[11];
-    const double *o_dec2 = push_table(T, qk_h_dec2_98, 98), *o_dec3 = push_table(T, qk_h_dec3_147, 147),
-                 *o_dec5 = push_table(T, qk_h_dec5_245, 245), *o_rs65 = push_table(T, qk_h_rs65_125, 125),
-                 *o_hb = push_table(T, hb43, 43), *o_s53 = push_table(T, qk_h_sdriq53_55, 55),
-                 *o_s111 = push_table(T, qk_h_sdriq111_114, 114), *o_s133 = push_table(T, qk_h_sdriq133_136, 136),
-                 *o_s167 = push_table(T, qk_h_sdriq167_174, 174), *o_s185 = push_table(T, qk_h_sdriq185_189, 189),
-                 *o_a3 = push_table(T, qk_h_aud24p3_100, 100), *o_a4 = push_table(T, qk_h_aud24p4_50, 50),
-                 *o_a6 = push_table(T, qk_h_aud24p6_36, 36), *o_fm = push_table(T, qk_h_fmhp_309, 309);
-    HIPCHECK(hipMalloc(&e->d_coefs, T.host.size() * sizeof(double)));
-    HIPCHECK(hipMemcpy(e->d_coefs, T.host.data(), T.host.size() * sizeof(double), hipMemcpyHostToDevice));
-#define FIX(dst, off) e->dst = e->d_coefs + reinterpret_cast<size_t>(off)
-    FIX(h_dec2, o_dec2); FIX(h_dec3, o_dec3); FIX(h_dec5, o_dec5); FIX(h_rs65, o_rs65); FIX(h_hbdec, o_hb);
-    FIX(h_s53, o_s53); FIX(h_s111, o_s111); FIX(h_s133, o_s133); FIX(h_s167, o_s167); FIX(h_s185, o_s185);
-    FIX(h_a24p3, o_a3); FIX(h_a24p4, o_a4); FIX(h_a24p6, o_a6); FIX(h_fmhp, o_fm);
-#undef FIX
     int rc = build_front(e);
     if (rc != QK_OK) return rc;
     // mixer state
@@ -494,7 +481,6 @@ static int engine_init(qk_engine *e)
     HIPCHECK(hipMalloc(&e->d_tabC, nrx * 64 * sizeof(double2)));
     HIPCHECK(hipMalloc(&e->d_mix_on, nrx * sizeof(int)));
     HIPCHECK(hipMemset(e->d_mix_on, 0, nrx * sizeof(int)));
-    HIPCHECK(hipMalloc(&e->d_in, (size_t)cfg.max_block * sizeof(double2)));
     e->tune.assign(nrx, 0); e->mode.assign(nrx, QK_USB); e->cls.assign(nrx, CL_SSB);
     e->ntaps.assign(nrx, 0); e->bandwidth.assign(nrx, 0); e->start_offset.assign(nrx, 0);
     e->out_count.assign(nrx, 0);
@@ -535,6 +521,39 @@ static int engine_init(qk_engine *e)
     if (rc != QK_OK) return rc;
     rc = upload_members(e);
     if (rc != QK_OK) return rc;
+    return QK_OK;
+}
+
+static int engine_init(qk_engine *e)
+{
+    const qk_config &cfg = e->cfg;
+    HIPCHECK(hipSetDevice(cfg.device));
+    HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->nrx = cfg.n_receivers;
+    // coefficient tables
+    DevTables T;
+    double hb43[43] = {0};
+    static const double c12[12] = { HB_C0, HB_C1, HB_C2, HB_C3, HB_C4, HB_C5, HB_C6, HB_C7, HB_C8, HB_C9, HB_C10, HB_C11 };
+    for (int k = 0; k < 11; k++) { hb43[2 * k] = c12[k]; hb43[42 - 2 * k] = c12[k]; }
+    hb43[21] = c12[11];
+    const double *o_dec2 = push_table(T, qk_h_dec2_98, 98), *o_dec3 = push_table(T, qk_h_dec3_147, 147),
+                 *o_dec5 = push_table(T, qk_h_dec5_245, 245), *o_rs65 = push_table(T, qk_h_rs65_125, 125),
+                 *o_hb = push_table(T, hb43, 43), *o_s53 = push_table(T, qk_h_sdriq53_55, 55),
+                 *o_s111 = push_table(T, qk_h_sdriq111_114, 114), *o_s133 = push_table(T, qk_h_sdriq133_136, 136),
+                 *o_s167 = push_table(T, qk_h_sdriq167_174, 174), *o_s185 = push_table(T, qk_h_sdriq185_189, 189),
+                 *o_a3 = push_table(T, qk_h_aud24p3_100, 100), *o_a4 = push_table(T, qk_h_aud24p4_50, 50),
+                 *o_a6 = push_table(T, qk_h_aud24p6_36, 36), *o_fm = push_table(T, qk_h_fmhp_309, 309);
+    HIPCHECK(hipMalloc(&e->d_coefs, T.host.size() * sizeof(double)));
+    HIPCHECK(hipMemcpy(e->d_coefs, T.host.data(), T.host.size() * sizeof(double), hipMemcpyHostToDevice));
+#define FIX(dst, off) e->dst = e->d_coefs + reinterpret_cast<size_t>(off)
+    FIX(h_dec2, o_dec2); FIX(h_dec3, o_dec3); FIX(h_dec5, o_dec5); FIX(h_rs65, o_rs65); FIX(h_hbdec, o_hb);
+    FIX(h_s53, o_s53); FIX(h_s111, o_s111); FIX(h_s133, o_s133); FIX(h_s167, o_s167); FIX(h_s185, o_s185);
+    FIX(h_a24p3, o_a3); FIX(h_a24p4, o_a4); FIX(h_a24p6, o_a6); FIX(h_fmhp, o_fm);
+#undef FIX
+    int rc = QK_OK;
+    HIPCHECK(hipMalloc(&e->d_in, (size_t)cfg.max_block * sizeof(double2)));
+    if (e->nrx > 0) { rc = init_receivers(e); if (rc != QK_OK) return rc; }
+    if (cfg.fft_size > 0) { rc = init_spectrum(e); if (rc != QK_OK) return rc; }
     e->ev_pool.resize(EV_POOL);
     for (auto &ev : e->ev_pool) HIPCHECK(hipEventCreate(&ev));
     HIPCHECK(hipDeviceSynchronize());
@@ -576,6 +595,138 @@ struct Timer {      // bucket 0..7 = QK_KT_*, 8 = whole block
 }  // namespace
 
 static inline dim3 grid1(int n, int planes, int nz) { return dim3((unsigned)((n + 255) / 256), (unsigned)planes, (unsigned)nz); }
+
+
+// ---------------------------------------------------------------------------------- display spectrum
+static int init_spectrum(qk_engine *e)
+{
+    const int N = e->cfg.fft_size, W = e->cfg.data_width;
+    if (N < 64 || (N & (N - 1))) return fail(QK_EUNSUPPORTED, "fft_size must be a power of two >= 64 (mixed-radix sizes: not yet)");
+    if (W < 1 || W > N) return fail(QK_EINVAL, "data_width must be in [1, fft_size]");
+    e->fftN = N; e->fftW = W; e->fftN1 = N > 4096 ? N / 4096 : 1;
+    if (e->fftN1 > 4096) return fail(QK_EUNSUPPORTED, "fft_size above 2^24");
+    std::vector<double> win(N);
+    for (int i = 0, j = -N / 2; i < N; i++, j++) win[i] = 0.5 + 0.5 * cos(2. * M_PI * j / N);   // quisk.c:5091-5096
+    std::vector<double2> tw(4096), lo(1024), hi(std::max(1, N / 1024));
+    for (int j = 0; j < 4096; j++) tw[j] = make_double2(cos(2.0 * M_PI * j / 4096), -sin(2.0 * M_PI * j / 4096));
+    for (int j = 0; j < 1024; j++) lo[j] = make_double2(cos(2.0 * M_PI * j / N), -sin(2.0 * M_PI * j / N));
+    for (size_t j = 0; j < hi.size(); j++) {
+        const double t = 2.0 * M_PI * (double)j * 1024.0 / N;
+        hi[j] = make_double2(cos(t), -sin(t));
+    }
+    HIPCHECK(hipMalloc(&e->d_window, sizeof(double) * N));
+    HIPCHECK(hipMemcpy(e->d_window, win.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&e->d_tw4096, sizeof(double2) * 4096));
+    HIPCHECK(hipMemcpy(e->d_tw4096, tw.data(), sizeof(double2) * 4096, hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&e->d_tw_lo, sizeof(double2) * 1024));
+    HIPCHECK(hipMemcpy(e->d_tw_lo, lo.data(), sizeof(double2) * 1024, hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&e->d_tw_hi, sizeof(double2) * hi.size()));
+    HIPCHECK(hipMemcpy(e->d_tw_hi, hi.data(), sizeof(double2) * hi.size(), hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&e->d_fft_stage, sizeof(double2) * N));
+    if (e->fftN1 > 1) HIPCHECK(hipMalloc(&e->d_fft_Y, sizeof(double2) * N));
+    HIPCHECK(hipMalloc(&e->d_fft_avg, sizeof(double) * N));
+    HIPCHECK(hipMemset(e->d_fft_avg, 0, sizeof(double) * N));
+    e->band_cap = N / 2 + 2;
+    HIPCHECK(hipMalloc(&e->d_band, sizeof(double) * e->band_cap));
+    HIPCHECK(hipMalloc(&e->d_meter, sizeof(double)));
+    HIPCHECK(hipMemset(e->d_meter, 0, sizeof(double)));
+    HIPCHECK(hipMalloc(&e->d_graph, sizeof(double) * W));
+    HIPCHECK(hipMalloc(&e->d_pix, sizeof(double) * W));
+    HIPCHECK(hipMalloc(&e->d_k0, sizeof(int) * W));
+    return QK_OK;
+}
+
+// one complete frame of fft_size samples at `frame` (device): window, FFT, S-meter bins, magnitude average
+static void fft_frame(qk_engine *e, const double2 *frame)
+{
+    const int N = e->fftN;
+    FftArgs a{};
+    a.x = frame; a.window = e->d_window; a.tw4096 = e->d_tw4096; a.tw_lo = e->d_tw_lo; a.tw_hi = e->d_tw_hi;
+    a.Y = e->d_fft_Y; a.avg = e->d_fft_avg; a.band = e->d_band; a.N = N; a.N1 = e->fftN1;
+    // S-meter pass band of receiver 0 (quisk.c:4659-4667)
+    const int fs = e->cfg.sample_rate;
+    const int bw = e->nrx > 0 ? e->bandwidth[0] : 0;
+    const int tune = e->nrx > 0 ? e->tune[0] : 0, off = e->nrx > 0 ? e->start_offset[0] : 0;
+    const double d2 = (double)bw * N / fs;
+    const int i0 = (int)((double)(tune + off) * N / fs + 0.5);
+    const int nw = (int)(floor(d2) + 0.01);
+    const bool meter_on = (i0 > -N / 2 && i0 + nw + 1 < N / 2) && nw + 1 <= e->band_cap;
+    a.band_start = i0; a.band_count = meter_on ? nw + 1 : 0;
+    Timer tm(e, QK_KT_FFT);
+    if (e->fftN1 > 1) {
+        hipLaunchKernelGGL(k_fft_cols, dim3(e->fftN1), dim3(FFT_THREADS), 0, e->stream, a);
+        hipLaunchKernelGGL(k_fft_rows, dim3(e->fftN1), dim3(FFT_THREADS), 0, e->stream, a);
+    } else {
+        switch (N) {
+        case 64: hipLaunchKernelGGL(k_fft_small<64>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
+        case 128: hipLaunchKernelGGL(k_fft_small<128>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
+        case 256: hipLaunchKernelGGL(k_fft_small<256>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
+        case 512: hipLaunchKernelGGL(k_fft_small<512>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
+        case 1024: hipLaunchKernelGGL(k_fft_small<1024>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
+        case 2048: hipLaunchKernelGGL(k_fft_small<2048>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
+        default: hipLaunchKernelGGL(k_fft_small<4096>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
+        }
+    }
+    if (meter_on)
+        hipLaunchKernelGGL(k_meter_accum, dim3(1), dim3(64), 0, e->stream, e->d_band, nw, d2 - nw, e->d_meter);
+    e->fft_count++;
+    e->stats.fft_frames++;
+}
+
+// FFT staging (quisk.c:2324-2348): consecutive, non-overlapping frames of the PRE-mixer samples.  The reference
+// queues at most four frames for the GUI thread and drops the rest (fft_error); here every frame is
+// transformed as soon as it is complete.
+static int feed_spectrum(qk_engine *e, const double2 *x, int n)
+{
+    const int N = e->fftN;
+    int pos = 0;
+    while (pos < n) {
+        if (e->fft_fill == 0 && n - pos >= N) {         // whole frame straight from the input block
+            fft_frame(e, x + pos);
+            pos += N;
+            continue;
+        }
+        const int take = std::min(N - e->fft_fill, n - pos);
+        HIPCHECK(hipMemcpyAsync(e->d_fft_stage + e->fft_fill, x + pos, sizeof(double2) * take, hipMemcpyDeviceToDevice, e->stream));
+        e->fft_fill += take; pos += take;
+        if (e->fft_fill == N) { fft_frame(e, e->d_fft_stage); e->fft_fill = 0; }
+    }
+    return QK_OK;
+}
+
+static int release_graph(qk_engine *e, double zoom, double deltaf, double *out, int data_width, double *smeter)
+{
+    const int N = e->fftN, W = e->fftW, count = e->fft_count;
+    if (data_width != W) return fail(QK_EINVAL, "data_width differs from the engine's");
+    if (count <= 0) return 0;
+    int n = (int)(zoom * (double)N / W + 0.5);                      // quisk.c:4715-4717
+    if (n < 1) n = 1;
+    std::vector<int> k0(W);
+    bool alias = false;
+    for (int i = 0; i < W; i++) {
+        k0[i] = (int)(N * (deltaf / e->cfg.sample_rate + zoom * ((double)i / W - 0.5) + 0.5) + 0.1);   // quisk.c:4720-4721
+        if (i >= 1 && k0[i] < i && k0[i] + n - 1 >= 0) alias = true;   // would read a pixel already written in place
+    }
+    HIPCHECK(hipMemcpyAsync(e->d_k0, k0.data(), sizeof(int) * W, hipMemcpyHostToDevice, e->stream));
+    ReleaseArgs ra{e->d_fft_avg, e->d_graph, e->d_k0, N, e->fftN1, W, n,
+                   20.0 * (log10((double)count) + log10((double)N) + 31.0 * log10(2.0))};          // quisk.c:4741-4742
+    if (alias) hipLaunchKernelGGL(k_graph_release_inplace, dim3(1), dim3(256), 0, e->stream, ra, e->d_pix);
+    else hipLaunchKernelGGL(k_graph_release, dim3((W + 3) / 4), dim3(256), 0, e->stream, ra);
+    double meter = 0;
+    HIPCHECK(hipMemcpyAsync(out, e->d_graph, sizeof(double) * W, hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipMemcpyAsync(&meter, e->d_meter, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPCHECK(hipMemsetAsync(e->d_fft_avg, 0, sizeof(double) * N, e->stream));
+    HIPCHECK(hipMemsetAsync(e->d_meter, 0, sizeof(double), e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    const double scale = 1.0 / 2147483647.0 / N;                    // quisk.c:4728-4737
+    double sm = meter * scale * scale / count;
+    sm = sm > 0 ? 10.0 * log10(sm) : -160.0;
+    sm += 4.25969;
+    e->smeter = sm;
+    if (smeter) *smeter = sm;
+    e->fft_count = 0;
+    return count;
+}
 
 // run one chain over `nlist` receivers; `input` is the stream feeding stage.in == -1
 static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_list, int nlist)
@@ -683,6 +834,14 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     if (n < 0 || n > e->cfg.max_block) return fail(QK_ERANGE, "block larger than max_block");
     if (n == 0) { for (auto &c : e->out_count) c = 0; return QK_OK; }
     Timer block_timer(e, 8);
+    // ---- display spectrum: frames of the samples as they arrive, before the mixer (quisk.c:2324-2348) ----
+    if (e->fftN > 0) { int rcs = feed_spectrum(e, x, n); if (rcs != QK_OK) return rcs; }
+    if (e->nrx == 0) {
+        HIPCHECK(hipGetLastError());
+        e->stats.samples_in += n;
+        e->stats.blocks += 1;
+        return QK_OK;
+    }
     const int S = e->S;
     Chain &F = e->front;
     // ---- front end ----
@@ -799,7 +958,7 @@ int qk_create(qk_engine **out, const qk_config *cfg)
 {
     if (!out || !cfg) return fail(QK_EINVAL, "null argument");
     *out = nullptr;
-    if (cfg->sample_rate < 41000 || cfg->n_receivers < 1 || cfg->max_block < 1)
+    if (cfg->sample_rate < 41000 || cfg->n_receivers < 0 || cfg->max_block < 1 || (cfg->n_receivers == 0 && cfg->fft_size <= 0))
         return fail(QK_EINVAL, "bad sample_rate / n_receivers / max_block");
     const int pr = cfg->playback_rate / 48000;
     if (cfg->playback_rate % 48000 || (pr != 1 && pr != 2 && pr != 4 && pr != 8))
@@ -827,7 +986,9 @@ void qk_destroy(qk_engine *e)
     for (auto &c : e->cls_chain) free_chain(c);
     for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
     void *ptrs[] = {e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps,
-                    e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_out};
+                    e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_out,
+                    e->d_fft_stage, e->d_fft_Y, e->d_tw4096, e->d_tw_lo, e->d_tw_hi, e->d_window, e->d_fft_avg, e->d_band,
+                    e->d_meter, e->d_graph, e->d_pix, e->d_k0};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ev : e->ev_pool) if (ev) hipEventDestroy(ev);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -986,12 +1147,13 @@ int qk_audio_device(qk_engine *e, const double **dev_ptr, size_t *stride)
 int qk_get_graph(qk_engine *e, double zoom, double deltaf, double *out, int data_width, double *smeter)
 {
     ENGINE_ENTER(e);
-    (void)zoom; (void)deltaf; (void)out; (void)data_width; (void)smeter;
-    if (e->cfg.fft_size <= 0) return fail(QK_EINVAL, "engine created without a display FFT");
-    return fail(QK_EUNSUPPORTED, "display FFT not implemented yet");
+    if (e->fftN <= 0) return fail(QK_EINVAL, "engine created without a display FFT");
+    if (!out) return fail(QK_EINVAL, "null output");
+    return release_graph(e, zoom, deltaf, out, data_width, smeter);
 }
-int qk_graph_pending(qk_engine *e) { ENGINE_ENTER(e); return 0; }
-int qk_graph_device(qk_engine *e, const double **dev_ptr) { ENGINE_ENTER(e); if (dev_ptr) *dev_ptr = nullptr; return QK_OK; }
+int qk_graph_pending(qk_engine *e) { ENGINE_ENTER(e); return e->fft_count; }
+int qk_graph_device(qk_engine *e, const double **dev_ptr) { ENGINE_ENTER(e); if (dev_ptr) *dev_ptr = e->d_graph; return QK_OK; }
+double qk_get_smeter(qk_engine *e) { return e ? e->smeter : 0.0; }
 
 int qk_get_filter_rate(int sample_rate, int mode, int bandwidth) { return filter_rate(sample_rate, mode, bandwidth); }
 int qk_plan_decimation(int sample_rate, int *d2, int *d3, int *d5) { return plan_decimation(sample_rate, d2, d3, d5); }

@@ -60,6 +60,8 @@ def lib():
     L.qk_audio_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.qk_get_graph.argtypes = [vp, C.c_double, C.c_double, vp, C.c_int, dp]
     L.qk_graph_pending.argtypes = [vp]
+    L.qk_get_smeter.argtypes = [vp]
+    L.qk_get_smeter.restype = C.c_double
     L.qk_graph_device.argtypes = [vp, C.POINTER(vp)]
     L.qk_get_filter_rate.argtypes = [C.c_int, C.c_int, C.c_int]
     L.qk_plan_decimation.argtypes = [C.c_int, ip, ip, ip]
@@ -203,6 +205,9 @@ class Engine:
 
     def export_audio_device(self, dst_dev_ptr, dst_stride):
         _check(self.L.qk_export_audio_device(self.h, C.c_void_p(int(dst_dev_ptr)), int(dst_stride)))
+
+    def graph_pending(self):
+        return _check(self.L.qk_graph_pending(self.h))
 
     def stats(self):
         st = QkStats()

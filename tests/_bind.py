@@ -232,3 +232,31 @@ def ref():
 def ref_table(symbol, n):
     arr = (C.c_double * n).in_dll(ref(), symbol)
     return np.array(arr[:], dtype=np.float64)
+
+
+class OracleGraph:
+    """get_graph restated (quisk.c:4602-4759): feed whole frames, then release."""
+
+    def __init__(self, fft_size, data_width, sample_rate):
+        self.L = oracle()
+        self.g = OGraph()
+        self.N, self.W = fft_size, data_width
+        self.L.qko_graph_init(C.byref(self.g), fft_size, data_width, sample_rate)
+
+    def set_passband(self, rx_tune, start_offset, bandwidth):
+        self.L.qko_graph_set_passband(C.byref(self.g), int(rx_tune), int(start_offset), int(bandwidth))
+
+    def add_frames(self, x):
+        assert len(x) % self.N == 0
+        for i in range(0, len(x), self.N):
+            fr = np.array(x[i:i + self.N], dtype=np.complex128, copy=True)
+            self.L.qko_graph_add_frame(C.byref(self.g), fr)
+
+    def release(self, zoom=1.0, deltaf=0.0):
+        out = np.zeros(self.W)
+        sm = C.c_double(0)
+        n = self.L.qko_graph_release(C.byref(self.g), zoom, deltaf, out, C.byref(sm))
+        return n, out, sm.value
+
+    def close(self):
+        self.L.qko_graph_free(C.byref(self.g))
