@@ -70,6 +70,7 @@ struct Chain {
     // fractional decimator (cFracDecim, quisk.c:570-613): the position recurrence runs on the host
     double frac_dindex = 1.0;
     int *d_frac_idx = nullptr; double *d_frac_pos = nullptr; int frac_cap = 0;
+    double *d_frac_state = nullptr;
 };
 
 struct DevTables { std::vector<double> host; double *dev = nullptr; };
@@ -260,6 +261,7 @@ static void free_chain(Chain &c)
     if (c.d_members) hipFree(c.d_members);
     if (c.d_frac_idx) hipFree(c.d_frac_idx);
     if (c.d_frac_pos) hipFree(c.d_frac_pos);
+    if (c.d_frac_state) hipFree(c.d_frac_state);
     c = Chain();
 }
 
@@ -395,6 +397,8 @@ static int build_class(qk_engine *e, int cl)
         c.frac_cap = b.cur_cap + 8;
         HIPCHECK(hipMalloc(&c.d_frac_idx, sizeof(int) * c.frac_cap));
         HIPCHECK(hipMalloc(&c.d_frac_pos, sizeof(double) * c.frac_cap));
+        HIPCHECK(hipMalloc(&c.d_frac_state, sizeof(double)));
+        { const double one = 1.0; HIPCHECK(hipMemcpy(c.d_frac_state, &one, sizeof(double), hipMemcpyHostToDevice)); }   // dindex = 1 (quisk.c:575)
     }
     // ... then interpolation to the play rate (quisk.c:2535-2553); mono, so one plane carries both channels
     for (int r = e->cfg.playback_rate / 48000; r > 1; r /= 2) b.hbint(1, T_B);
@@ -806,8 +810,26 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             }
             break;
         }
-        case ST_FRAC:
-            return fail(QK_EUNSUPPORTED, "fractional decimator stage not implemented yet");
+        case ST_FRAC: {
+            // the reference's position recurrence (quisk.c:581-609), run for this block's n_in inputs
+            const double fdecim = e->decim_srate / 48000.0;
+            const double step = fdecim - 1;
+            int n_out = 0;
+            for (int i = 0; i < n_in; i++) {
+                if (c.frac_dindex < 2) { n_out++; c.frac_dindex += step; }
+                else c.frac_dindex -= 1;
+            }
+            out.n = n_out;
+            if (n_out > c.frac_cap) return fail(QK_ERANGE, "internal: fractional decimator output exceeds its buffer");
+            if (n_in > 0)
+                hipLaunchKernelGGL(k_frac_positions, dim3(1), dim3(64), 0, e->stream, c.d_frac_state, step, n_in, c.d_frac_idx, c.d_frac_pos);
+            if (n_out > 0) {
+                FracArgs a{in.view(), out.view(), c.d_frac_idx, c.d_frac_pos, n_out, d_list};
+                Timer tm(e, st.timer);
+                hipLaunchKernelGGL(k_fracdecim, grid1(n_out, 1, nlist), dim3(256), 0, e->stream, a);
+            }
+            break;
+        }
         }
     }
     return QK_OK;

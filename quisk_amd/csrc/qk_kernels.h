@@ -357,6 +357,37 @@ __global__ __launch_bounds__(256) void k_hb_interp(HbInterpArgs a)
     o[1] = acc * 2;
 }
 
+// Fractional decimator (cFracDecim, quisk.c:570-613): 4-point Lagrange interpolation at position dindex
+// between the last four samples.  The position recurrence does not depend on the data, so the host runs it
+// (same operations, same order) and hands over, per output, the index of the newest sample and dindex.
+// The position recurrence itself, on one lane (the host runs the same recurrence to learn the output count).
+__global__ void k_frac_positions(double *dindex_state, double step, int n_in, int *idx, double *pos)
+{
+#pragma clang fp contract(off)
+    if (threadIdx.x || blockIdx.x) return;
+    double d = *dindex_state;
+    int m = 0;
+    for (int i = 0; i < n_in; i++) {
+        if (d < 2) { idx[m] = i; pos[m] = d; m++; d += step; }
+        else d -= 1;
+    }
+    *dindex_state = d;
+}
+struct FracArgs { StreamView in, out; const int *idx; const double *pos; int n_out; const int *rx_list; };
+__global__ __launch_bounds__(256) void k_fracdecim(FracArgs a)
+{
+#pragma clang fp contract(off)
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= a.n_out) return;
+    const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
+    const double *__restrict__ p = sv_ptr(a.in, rx, 0) + a.idx[m];
+    const double d = a.pos[m];
+    const double c0 = p[-3], c1 = p[-2], c2 = p[-1], c3 = p[0];
+    const double xm0 = d - 0, xm1 = d - 1, xm2 = d - 2, xm3 = d - 3;
+    sv_ptr(a.out, rx, 0)[m] = (xm1 * xm2 * xm3 * c0 / -6.0 + xm0 * xm2 * xm3 * c1 / 2.0 +
+                               xm0 * xm1 * xm3 * c2 / -2.0 + xm0 * xm1 * xm2 * c3 / 6.0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Receive band-pass + detector.
 //   cRxFilterOut (quisk.c:1154-1192): I taps on the real plane, Q taps on the imaginary plane.

@@ -133,6 +133,7 @@ class OracleRx:
                  agc_gain=80.0, agc_release_time=1.0):
         self.L = oracle()
         self.h = self.L.qko_rx_new(sample_rate, playback_rate)
+        self.ratio = playback_rate / sample_rate
         self.L.qko_rx_set_mode(self.h, mode)
         self.L.qko_rx_set_tune(self.h, tune)
         self.L.qko_rx_set_agc(self.h, agc_gain, agc_release_time)
@@ -144,11 +145,15 @@ class OracleRx:
     def set_tune(self, hz):
         self.L.qko_rx_set_tune(self.h, hz)
 
+    def _cap(self, n):
+        """work-buffer size: the chain runs in place; only a play rate above the input rate makes it grow"""
+        return max(n, int(n * self.ratio * 1.1)) + 4096
+
     def process(self, x):
         """x: complex128 block (<= 66000); returns the stereo audio block."""
         buf = np.array(x, dtype=np.complex128, copy=True)
         cap = max(len(buf), 16)
-        work = np.zeros(9 * cap + 64, dtype=np.complex128)
+        work = np.zeros(self._cap(cap), dtype=np.complex128)
         work[:len(buf)] = buf
         m = self.L.qko_rx_process(self.h, work, len(buf))
         return work[:m].copy()
@@ -156,7 +161,7 @@ class OracleRx:
     def process_parts(self, x):
         """(pre-AGC stereo block at the play rate, final block)"""
         n = len(x)
-        work = np.zeros(9 * n + 64, dtype=np.complex128)
+        work = np.zeros(self._cap(n), dtype=np.complex128)
         work[:n] = x
         m = self.L.qko_rx_pre_agc(self.h, work, n)
         pre = work[:m].copy()

@@ -97,3 +97,43 @@ def test_mixed_modes_retune_midstream():
         pr.step(x[i * block:(i + 1) * block])
     pr.close()
     pr.check()
+
+
+@pytest.mark.parametrize("fs,block,nblk", [(48000, 4800, 6), (96000, 9600, 6), (240000, 24000, 6), (250000, 25000, 6),
+                                           (384000, 38400, 5), (960000, 48000, 6)])
+def test_other_sample_rates(fs, block, nblk):
+    """Rates whose plans use the other stages of quisk_process_decimate: no decimation, FIR /2 only, /5, the
+    6/5 x 4/5 resampler (250 k), three half-bands (384 k), /5 + half-bands (960 k)."""
+    pr = _stream(fs, [3, 4], [int(0.2 * fs), int(-0.3 * fs)], [block] * nblk, 31)
+    pr.check()
+
+
+@pytest.mark.parametrize("fs", [53333, 111111, 133333, 185185, 370370, 740740, 1333333])
+def test_sdriq_rates(fs):
+    """The SDR-IQ special cases (quisk.c:1611-1644); all end at a rate other than 48000 and go through
+    the fractional decimator (quisk.c:2528-2532)."""
+    block = fs // 10
+    pr = _stream(fs, [3], [int(0.21 * fs)], [block] * 6, 41)
+    pr.check()
+
+
+def test_c4_plan_61440k_mixed_modes():
+    """BASELINE config 4's rate: 61.44 Msps -> 3 half-bands, /3, /5, /5, /2, 6/5 x 4/5 resampler (49152) and the
+    fractional decimator to 48 k; mixed SSB/AM/FM receivers."""
+    fs = 61440000
+    nrx = 4
+    tunes = tune_offsets(nrx, fs)
+    modes = mode_mix(nrx, "mixed")
+    pr = _stream(fs, modes, tunes, [65536, 40000] + [1 << 20] * 8, 1004, max_block=1 << 20)
+    assert pr.samples > 4 * 6000
+    pr.check()
+
+
+def test_long_run_mixer_drift():
+    """2^24 samples through one receiver: the reference's tune vector is a never-renormalised recurrence
+    (quisk.c:2356-2360) whose systematic drift a closed-form phasor would not follow; the engine's power tables do."""
+    fs = 1536000
+    blocks = [1 << 20] * 16
+    pr = _stream(fs, [3], [345678], blocks, 1002)
+    assert pr.samples == 16 * 32768
+    pr.check()
