@@ -92,8 +92,9 @@ def main():
     total_rx = nrx * world
     all_tunes = tune_offsets(total_rx, fs)
     all_modes = mode_mix(total_rx, a.mix)
-    tunes = all_tunes[rank * nrx:(rank + 1) * nrx]
-    modes = all_modes[rank * nrx:(rank + 1) * nrx]
+    from quisk_amd.shard import receiver_slice, gather_audio, max_over_ranks
+    lo, hi = receiver_slice(total_rx, world, rank)
+    tunes, modes = all_tunes[lo:hi], all_modes[lo:hi]
 
     eng = Engine(fs, n_receivers=nrx, max_block=block, device=local)
     for r in range(nrx):
@@ -131,24 +132,22 @@ def main():
     dt = time.perf_counter() - t0
     st = eng.stats()
     eng.set_timing(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt, torch.device("cuda", local))
 
     # RCCL gather of the audio outputs (outside the timed region)
     gather_ms = None
     if world > 1:
-        out, counts = eng.audio_all()
-        stride = int(counts.max())
+        counts = torch.tensor([eng.L.qk_audio_count(eng.h, r) for r in range(nrx)], dtype=torch.int64, device="cuda")
+        stride = int(counts.max().item())
         send = torch.empty((nrx, stride, 2), dtype=torch.float64, device="cuda")
         eng.export_audio_device(send.data_ptr(), stride)
-        recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        dist.gather(send, recv, dst=0)
+        audio, cnt = gather_audio(send, counts, dst=0)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0:
+            assert audio.shape[0] == total_rx and int(cnt.min().item()) > 0
 
     from quisk_amd import plan_decimation
     _, d2, _, _ = plan_decimation(fs)
