@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_mixhist_update(FrontArgs a, double2 *hi
 template <int CHUNK> struct FeLayout {
     // level s: 4 sub-arrays (plane*2 + phase), each SUB(s) doubles; O arrays start one double late so that
     // index m0+1 (m0 multiple of 6) is 16-byte aligned, E arrays read from m0+12 (even).
-    static __host__ __device__ constexpr int sub(int s) { return (CHUNK >> (s + 1)) + FE_HIST + 12; }
+    static __host__ __device__ constexpr int sub(int s) { return (CHUNK >> (s + 1)) + FE_HIST + 14; }
     static __host__ __device__ constexpr int level_off(int s) { int o = 0; for (int i = 0; i < s; i++) o += 4 * sub(i); return o; }
     static __host__ __device__ constexpr int total(int S) { return level_off(S) + 2 * (CHUNK / 64 + 2) + 128; }
 };
@@ -143,22 +143,25 @@ template <int CHUNK> struct FeLayout {
 template <int CHUNK>
 __device__ __forceinline__ double *fe_arr(double *smem, int s, int plane, int phase)
 {
-    // phase 1 (O) is shifted by one double for alignment of the vector reads
-    return smem + FeLayout<CHUNK>::level_off(s) + (plane * 2 + phase) * FeLayout<CHUNK>::sub(s) + phase;
+    // every sub-array starts 16-byte aligned; the odd-phase (O) arrays keep their samples one slot further on
+    // (sample j at index FE_HIST + 1 + j) so that the vector reads of hb45_block start on an even index
+    return smem + FeLayout<CHUNK>::level_off(s) + (plane * 2 + phase) * FeLayout<CHUNK>::sub(s);
 }
 
 // R consecutive outputs m0..m0+R-1 of one half-band stage from the polyphase arrays of its input level.
 __device__ __forceinline__ void hb45_block(const double *__restrict__ O, const double *__restrict__ E, int m0,
                                            double (&y)[FE_R])
 {
+    // O, E: 16-byte aligned sub-array bases; m0 is a multiple of FE_R (even).  Odd-phase sample j sits at
+    // O[FE_HIST + 1 + j], even-phase sample j at E[FE_HIST + j].
     double o[FE_R + 22];
     double e[FE_R];
-    const double2 *po = reinterpret_cast<const double2 *>(O + m0 + 1);      // O index of x[2(m0)+1 - 42] ...
+    const double2 *po = reinterpret_cast<const double2 *>(__builtin_assume_aligned(O, 16)) + (m0 / 2 + 1);   // O[m0 + 2 ...]
 #pragma unroll
-    for (int j = 0; j < (FE_R + 22) / 2; j++) { double2 v = po[j]; o[2 * j] = v.x; o[2 * j + 1] = v.y; }
-    const double2 *pe = reinterpret_cast<const double2 *>(E + m0 + 12);
+    for (int j = 0; j < (FE_R + 22) / 2; j++) { const double2 v = po[j]; o[2 * j] = v.x; o[2 * j + 1] = v.y; }
+    const double2 *pe = reinterpret_cast<const double2 *>(__builtin_assume_aligned(E, 16)) + (m0 / 2 + 6);   // E[m0 + 12 ...]
 #pragma unroll
-    for (int j = 0; j < FE_R / 2; j++) { double2 v = pe[j]; e[2 * j] = v.x; e[2 * j + 1] = v.y; }
+    for (int j = 0; j < FE_R / 2; j++) { const double2 v = pe[j]; e[2 * j] = v.x; e[2 * j + 1] = v.y; }
 #pragma unroll
     for (int r = 0; r < FE_R; r++) {
         // samples[k] = o[r+21-k]; pair k with 21-k, in the reference's order k = 0..10, then the centre tap
@@ -223,8 +226,9 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(FrontArgs a)
                     const long long hi = k + a.H;
                     v = hi >= 0 ? histp[hi] : make_double2(0.0, 0.0);
                 }
-                const int idx = FE_HIST + (i >> 1);
-                if (i & 1) { O0[idx] = v.x; O1[idx] = v.y; } else { E0[idx] = v.x; E1[idx] = v.y; }
+                const int idx = FE_HIST + (i >> 1) + (i & 1);           // odd phase: one slot further on
+                double *d0 = (i & 1) ? O0 : E0, *d1 = (i & 1) ? O1 : E1;
+                d0[idx] = v.x; d1[idx] = v.y;
             }
         }
         __syncthreads();
@@ -239,20 +243,23 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(FrontArgs a)
                 const int m0 = q * FE_R;
                 double y[FE_R];
                 hb45_block(fe_arr<CHUNK>(smem, s, plane, 1), fe_arr<CHUNK>(smem, s, plane, 0), m0, y);
+                const bool whole = m0 + FE_R <= n_out;
                 if (s + 1 < S) {
-                    double *En = fe_arr<CHUNK>(smem, s + 1, plane, 0), *On = fe_arr<CHUNK>(smem, s + 1, plane, 1);
-#pragma unroll
-                    for (int r = 0; r < FE_R; r++) {
-                        const int m = m0 + r;
-                        if (m < n_out) {
-                            if (m & 1) On[FE_HIST + (m >> 1)] = y[r]; else En[FE_HIST + (m >> 1)] = y[r];
-                        }
-                    }
+                    // m0 is even: outputs r = 0, 2, 4 are even-phase samples m0/2 + r/2 of the next level, r = 1, 3, 5 odd-phase
+                    double *En = fe_arr<CHUNK>(smem, s + 1, plane, 0) + FE_HIST + (m0 >> 1);
+                    double *On = fe_arr<CHUNK>(smem, s + 1, plane, 1) + FE_HIST + 1 + (m0 >> 1);
+                    // (a partial last item writes a few values past the valid range: they land in the arrays' padding)
+                    En[0] = y[0]; On[0] = y[1]; En[1] = y[2]; On[1] = y[3]; En[2] = y[4]; On[2] = y[5];
                 } else if (emit) {
-                    double *op = (plane ? out1 : out0) + ((pos >> S) - a.J0);
+                    double *op = (plane ? out1 : out0) + ((pos >> S) - a.J0) + m0;
+                    if (whole) {
 #pragma unroll
-                    for (int r = 0; r < FE_R; r++)
-                        if (m0 + r < n_out) op[m0 + r] = y[r];
+                        for (int r = 0; r < FE_R; r++) op[r] = y[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < FE_R; r++)
+                            if (m0 + r < n_out) op[r] = y[r];
+                    }
                 }
             }
             __syncthreads();
@@ -264,14 +271,14 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(FrontArgs a)
             for (int w = t; w < S * 4 * FE_HIST; w += FE_THREADS, cnt++) {
                 const int s = w / (4 * FE_HIST), rem = w % (4 * FE_HIST);
                 const int sub = rem / FE_HIST, i = rem % FE_HIST;
-                keep[cnt] = fe_arr<CHUNK>(smem, s, sub >> 1, sub & 1)[(c >> (s + 1)) + i];
+                keep[cnt] = fe_arr<CHUNK>(smem, s, sub >> 1, sub & 1)[(c >> (s + 1)) + (sub & 1) + i];
             }
             __syncthreads();
             cnt = 0;
             for (int w = t; w < S * 4 * FE_HIST; w += FE_THREADS, cnt++) {
                 const int s = w / (4 * FE_HIST), rem = w % (4 * FE_HIST);
                 const int sub = rem / FE_HIST, i = rem % FE_HIST;
-                fe_arr<CHUNK>(smem, s, sub >> 1, sub & 1)[i] = keep[cnt];
+                fe_arr<CHUNK>(smem, s, sub >> 1, sub & 1)[(sub & 1) + i] = keep[cnt];
             }
         }
         pos += c;
