@@ -67,6 +67,7 @@ struct Chain {
     int aud = -1;              // stream index of the 48 kHz-class mono audio
     int play = -1;             // stream index of the audio at the playback rate (AGC input)
     int n_out = 0;             // audio samples of the last block
+    double *play_alt = nullptr; // ping-pong twin of streams[play]: the AGC of block b runs beside the chain of block b+1
     // fractional decimator (cFracDecim, quisk.c:570-613): the position recurrence runs on the host
     double frac_dindex = 1.0;
     int *d_frac_idx = nullptr; double *d_frac_pos = nullptr; int frac_cap = 0;
@@ -81,8 +82,13 @@ struct qk_engine {
     qk_config cfg{};
     std::mutex mu;
     hipStream_t stream = nullptr;
+    hipStream_t agc_stream = nullptr;      // the serial AGC pass of block b overlaps the chain of block b+1
+    hipEvent_t ev_chain = nullptr, ev_agc[2] = {nullptr, nullptr};
+    bool agc_pending = false;
     int nrx = 0, S = 0, tap_cap = DEFAULT_TAP_CAP;
     int fe_rate = 0, decim_srate = 0;
+    int fe_slots = 2304;       // resident one-wave workgroups of k_frontend_wave on the whole chip (occupancy query)
+    int fe_variant = 1;        // 1 = k_frontend_wave (one wave per span), 0 = k_frontend (256-thread workgroups); QK_FE_VARIANT
     int rate_case = 0;
     // input
     double2 *d_in = nullptr;
@@ -259,6 +265,7 @@ static void free_chain(Chain &c)
     for (auto &s : c.streams) if (s.d) hipFree(s.d);
     for (auto &st : c.stages) if (st.iir_state) hipFree(st.iir_state);
     if (c.d_members) hipFree(c.d_members);
+    if (c.play_alt) hipFree(c.play_alt);
     if (c.d_frac_idx) hipFree(c.d_frac_idx);
     if (c.d_frac_pos) hipFree(c.d_frac_pos);
     if (c.d_frac_state) hipFree(c.d_frac_state);
@@ -410,6 +417,12 @@ static int build_class(qk_engine *e, int cl)
     else if (in.hist < b.in_hist) return fail(QK_EINVAL, "internal: front stream history too small");
     rc = alloc_chain_streams(e, c);
     if (rc != QK_OK) return rc;
+    {
+        Stream &pl = c.streams[c.play];
+        const size_t bytes = (size_t)e->nrx * pl.rx_stride() * sizeof(double);
+        HIPCHECK(hipMalloc(&c.play_alt, bytes));
+        HIPCHECK(hipMemsetAsync(c.play_alt, 0, bytes, e->stream));
+    }
     if (cl == CL_FM) {
         // fm_1 starts at 10 + 0i (quisk.c:1763): it is the history sample in front of the first block
         Stream &f = c.streams[c.stages[0].out];
@@ -470,7 +483,23 @@ static int init_receivers(qk_engine *e)
     int rc = build_front(e);
     if (rc != QK_OK) return rc;
     // mixer state
-    e->H = (44 << e->S) + (1 << e->S) + 64;
+    e->H = (44 << e->S) + (1 << e->S) + 128;
+    if (const char *v = getenv("QK_FE_VARIANT")) e->fe_variant = atoi(v) ? 1 : 0;
+    {
+        int per_cu = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg.device) == hipSuccess) cus = prop.multiProcessorCount;
+        hipError_t oe = hipErrorUnknown;
+        switch (e->S) {
+        case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<1>, 64, 0); break;
+        case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<2>, 64, 0); break;
+        case 3: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<3>, 64, 0); break;
+        case 4: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<4>, 64, 0); break;
+        case 5: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<5>, 64, 0); break;
+        default: break;
+        }
+        if (oe == hipSuccess && per_cu > 0) e->fe_slots = per_cu * cus;
+    }
     e->nA = (cfg.max_block >> 12) + 2;
     const size_t nrx = e->nrx;
     for (int i = 0; i < 2; i++) {
@@ -533,6 +562,10 @@ static int engine_init(qk_engine *e)
     const qk_config &cfg = e->cfg;
     HIPCHECK(hipSetDevice(cfg.device));
     HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIPCHECK(hipStreamCreateWithFlags(&e->agc_stream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_chain, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_agc[0], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_agc[1], hipEventDisableTiming));
     e->nrx = cfg.n_receivers;
     // coefficient tables
     DevTables T;
@@ -570,6 +603,7 @@ int drain_events(qk_engine *e)
 {
     if (e->ev_pending.empty()) { e->ev_next = 0; return QK_OK; }
     HIPCHECK(hipStreamSynchronize(e->stream));
+    HIPCHECK(hipStreamSynchronize(e->agc_stream));
     for (auto &p : e->ev_pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, e->ev_pool[p.e0], e->ev_pool[p.e1]) != hipSuccess) continue;
@@ -581,18 +615,18 @@ int drain_events(qk_engine *e)
     return QK_OK;
 }
 struct Timer {      // bucket 0..7 = QK_KT_*, 8 = whole block
-    qk_engine *e; int bucket; int e0 = -1;
-    Timer(qk_engine *en, int b) : e(en), bucket(b)
+    qk_engine *e; int bucket; int e0 = -1; hipStream_t st;
+    Timer(qk_engine *en, int b, hipStream_t stream = nullptr) : e(en), bucket(b), st(stream ? stream : en->stream)
     {
         if (!e->timing || b < 0 || b > 8) return;
         if (e->ev_next + 2 > (int)e->ev_pool.size()) drain_events(e);
         e0 = e->ev_next; e->ev_next += 2;
-        hipEventRecord(e->ev_pool[e0], e->stream);
+        hipEventRecord(e->ev_pool[e0], st);
     }
     ~Timer()
     {
         if (e0 < 0) return;
-        hipEventRecord(e->ev_pool[e0 + 1], e->stream);
+        hipEventRecord(e->ev_pool[e0 + 1], st);
         e->ev_pending.push_back({bucket, e0, e0 + 1});
     }
 };
@@ -835,20 +869,25 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
     return QK_OK;
 }
 
-static void add_tails(TailArgs &ta, Chain &c)
+static void add_tails(TailArgs &ta, Chain &c, int skip)
 {
-    for (auto &s : c.streams) {
-        if (s.hist <= 0 || s.n <= 0) continue;
+    for (int i = 0; i < (int)c.streams.size(); i++) {
+        Stream &s = c.streams[i];
+        if (i == skip || s.hist <= 0 || s.n <= 0) continue;
         if (ta.count >= QK_MAX_TAILS) break;
-        ta.t[ta.count++] = TailDesc{s.d, s.rx_stride(), s.hist + s.cap, s.planes, s.hist, s.n};
+        ta.t[ta.count++] = TailDesc{s.d, s.rx_stride(), s.hist + s.cap, s.planes, s.hist, s.n, s.d};
     }
 }
 
 template <int S>
 static void launch_frontend(qk_engine *e, const FrontArgs &fa, int nspans)
 {
-    const size_t lds = FeLayout<FE_CHUNK>::total(S) * sizeof(double);
-    hipLaunchKernelGGL((k_frontend<S, FE_CHUNK>), dim3(nspans, e->nrx), dim3(FE_THREADS), lds, e->stream, fa);
+    if (e->fe_variant == 0) {
+        const size_t lds = FeLayout<FE_CHUNK>::total(S) * sizeof(double);
+        hipLaunchKernelGGL((k_frontend<S, FE_CHUNK>), dim3(nspans, e->nrx), dim3(FE_THREADS), lds, e->stream, fa);
+    } else {
+        hipLaunchKernelGGL((k_frontend_wave<S>), dim3(nspans, e->nrx), dim3(64), 0, e->stream, fa);
+    }
 }
 
 static int process_device(qk_engine *e, const double2 *x, int n)
@@ -884,8 +923,9 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         } else if (consumed > 0) {
             // spans: enough workgroups to fill 256 CUs several times over, but long enough that the warm-up
             // (44 * 2^S samples per span) stays a small fraction
-            const long long unit = FE_CHUNK;
-            long long want = std::max(1LL, (long long)(2048 / std::max(1, e->nrx)));
+            const long long unit = e->fe_variant ? FW_CHUNK : FE_CHUNK;
+            const long long target_wgs = e->fe_variant ? 2LL * e->fe_slots : 2048;
+            long long want = std::max(1LL, target_wgs / std::max(1, e->nrx));
             long long span = (consumed + want - 1) / want;
             span = std::max(span, 4 * unit);
             span = (span + unit - 1) / unit * unit;
@@ -912,57 +952,76 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     int rc = run_chain(e, F, F.streams[0], nullptr, e->nrx);
     if (rc != QK_OK) return rc;
     const Stream &dec = F.streams[F.aud];
-    // ---- per class: demodulate, audio chain, AGC ----
+    // ---- per class: demodulate and audio chain on the main stream ----
     for (int cl = 0; cl < CL_COUNT; cl++) {
         Chain &c = e->cls_chain[cl];
         const int nl = (int)c.members.size();
         if (!nl) continue;
+        // the play-rate stream is double-buffered: this block writes the twin whose history the previous block's
+        // tail copy prepared, while the AGC pass of the previous block may still read the other one
+        std::swap(c.streams[c.play].d, c.play_alt);
         rc = run_chain(e, c, dec, c.d_members, nl);
         if (rc != QK_OK) return rc;
-        Stream &play = c.streams[c.play];
-        const int m = play.n;
-        c.n_out = m;
-        if (m > (int)e->out_stride) return fail(QK_ERANGE, "internal: audio block exceeds the output stride");
-        if (m > 0) {
-            const int rate = e->cfg.playback_rate;
-            AgcArgs a{};
-            a.in = play.view(); a.gains = e->d_gains; a.gain_stride = e->gain_stride; a.n = m;
-            a.buf_size = rate * 15 / 1000; a.n_rx = nl;
-            a.ceiling = 0.7 * QK_CLIP32;                                         // Agc1 max_out, quisk.c:2181
-            a.time_release = 1.0 - exp(-1.0 / rate / e->agc_release_time);       // quisk.c:2045
-            a.release_gain = e->d_release_gain; a.mode = e->d_mode; a.state = e->d_agc;
-            a.out = e->d_out; a.out_stride = (long long)e->out_stride; a.rx_list = c.d_members;
-            a.started = e->d_agc_started;
-            Timer tm(e, QK_KT_AGC);
-            hipLaunchKernelGGL(k_agc_gain, dim3(nl), dim3(64), 0, e->stream, a);
-            hipLaunchKernelGGL(k_agc_apply, grid1(m, 1, nl), dim3(256), 0, e->stream, a);
-        }
-        for (int r : c.members) e->out_count[r] = m;
+        c.n_out = c.streams[c.play].n;
+        if (c.n_out == 0) std::swap(c.streams[c.play].d, c.play_alt);     // nothing written: stay on the same twin
+        if (c.n_out > (int)e->out_stride) return fail(QK_ERANGE, "internal: audio block exceeds the output stride");
+        for (int r : c.members) e->out_count[r] = c.n_out;
     }
+    // ---- AGC on its own stream: serial in time per receiver (one wave each), so it runs beside the next
+    //      block's front end and FIR chain instead of in front of them ----
+    const int par = (int)(e->stats.blocks & 1);
+    HIPCHECK(hipEventRecord(e->ev_chain, e->stream));
+    HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_chain, 0));
+    for (int cl = 0; cl < CL_COUNT; cl++) {
+        Chain &c = e->cls_chain[cl];
+        const int nl = (int)c.members.size(), m = c.n_out;
+        if (!nl || m <= 0) continue;
+        const Stream &play = c.streams[c.play];
+        const int rate = e->cfg.playback_rate;
+        AgcArgs a{};
+        a.in = play.view(); a.gains = e->d_gains; a.gain_stride = e->gain_stride; a.n = m;
+        a.buf_size = rate * 15 / 1000; a.n_rx = nl;
+        a.ceiling = 0.7 * QK_CLIP32;                                         // Agc1 max_out, quisk.c:2181
+        a.time_release = 1.0 - exp(-1.0 / rate / e->agc_release_time);       // quisk.c:2045
+        a.release_gain = e->d_release_gain; a.mode = e->d_mode; a.state = e->d_agc;
+        a.out = e->d_out; a.out_stride = (long long)e->out_stride; a.rx_list = c.d_members;
+        a.started = e->d_agc_started;
+        Timer tm(e, QK_KT_AGC, e->agc_stream);
+        hipLaunchKernelGGL(k_agc_gain, dim3(nl), dim3(64), 0, e->agc_stream, a);
+        hipLaunchKernelGGL(k_agc_apply, grid1(m, 1, nl), dim3(256), 0, e->agc_stream, a);
+        for (int r : c.members)
+            if (!e->agc_started[r])
+                hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_agc_started + r), 1, 1, e->agc_stream);
+    }
+    HIPCHECK(hipEventRecord(e->ev_agc[par], e->agc_stream));
     // ---- carry stream tails ----
     {
         TailArgs ta{}; ta.count = 0; ta.rx_list = nullptr;
-        add_tails(ta, F);
+        add_tails(ta, F, -1);
         if (ta.count) hipLaunchKernelGGL(k_save_tails, dim3(ta.count, 2, e->nrx), dim3(256), 0, e->stream, ta);
+        // the play streams' tails go into the twin buffers, which the previous block's AGC pass may still be reading
+        if (e->agc_pending) HIPCHECK(hipStreamWaitEvent(e->stream, e->ev_agc[par ^ 1], 0));
         for (int cl = 0; cl < CL_COUNT; cl++) {
             Chain &c = e->cls_chain[cl];
             const int nl = (int)c.members.size();
             if (!nl) continue;
             TailArgs tb{}; tb.count = 0; tb.rx_list = c.d_members;
-            add_tails(tb, c);
+            add_tails(tb, c, c.play);
+            Stream &play = c.streams[c.play];
+            if (play.n > 0 && tb.count < QK_MAX_TAILS)
+                tb.t[tb.count++] = TailDesc{play.d, play.rx_stride(), play.hist + play.cap, play.planes, play.hist, play.n, c.play_alt};
             if (tb.count) hipLaunchKernelGGL(k_save_tails, dim3(tb.count, 2, nl), dim3(256), 0, e->stream, tb);
             if (c.n_out > 0) {
                 // A receiver's first process_agc call returns the block untouched and does NOT store it in the
                 // delay ring (quisk.c:2033-2050): the ring (= the play stream's history) stays zero.
-                Stream &play = c.streams[c.play];
                 for (int r : c.members) {
                     if (e->agc_started[r]) continue;
-                    hipMemsetAsync(play.d + (long long)r * play.rx_stride(), 0, sizeof(double) * play.hist, e->stream);
-                    hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_agc_started + r), 1, 1, e->stream);
+                    hipMemsetAsync(c.play_alt + (long long)r * play.rx_stride(), 0, sizeof(double) * play.hist, e->stream);
                     e->agc_started[r] = 1;
                 }
             }
         }
+        e->agc_pending = true;
     }
     HIPCHECK(hipGetLastError());
     e->stats.samples_in += n;
@@ -1004,6 +1063,7 @@ void qk_destroy(qk_engine *e)
     if (!e) return;
     hipSetDevice(e->cfg.device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->agc_stream) hipStreamSynchronize(e->agc_stream);
     free_chain(e->front);
     for (auto &c : e->cls_chain) free_chain(c);
     for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
@@ -1013,6 +1073,9 @@ void qk_destroy(qk_engine *e)
                     e->d_meter, e->d_graph, e->d_pix, e->d_k0};
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ev : e->ev_pool) if (ev) hipEventDestroy(ev);
+    if (e->agc_stream) { hipStreamSynchronize(e->agc_stream); hipStreamDestroy(e->agc_stream); }
+    if (e->ev_chain) hipEventDestroy(e->ev_chain);
+    for (auto &ev : e->ev_agc) if (ev) hipEventDestroy(ev);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1021,13 +1084,14 @@ void qk_destroy(qk_engine *e)
     if (!(e)) return fail(QK_EINVAL, "null engine");                     \
     std::lock_guard<std::mutex> _lk((e)->mu);                            \
     HIPCHECK(hipSetDevice((e)->cfg.device))
+#define SYNC_ALL(e) do { HIPCHECK(hipStreamSynchronize((e)->stream)); HIPCHECK(hipStreamSynchronize((e)->agc_stream)); } while (0)
 #define RX_CHECK(e, rx) if ((rx) < 0 || (rx) >= (e)->nrx) return fail(QK_ERANGE, "receiver index out of range")
 
 int qk_set_tune(qk_engine *e, int rx, int tune_hz)
 {
     ENGINE_ENTER(e); RX_CHECK(e, rx);
     if (e->tune[rx] == tune_hz) return QK_OK;
-    HIPCHECK(hipStreamSynchronize(e->stream));
+    SYNC_ALL(e);
     e->tune[rx] = tune_hz;
     return upload_tune(e, rx);
 }
@@ -1038,7 +1102,7 @@ int qk_set_mode(qk_engine *e, int rx, int mode)
     const int cl = class_of_mode(mode);
     if (cl < 0) return fail(QK_EUNSUPPORTED, "mode needs an external codec or is not on the GPU path yet");
     if (e->mode[rx] == mode) return QK_OK;
-    HIPCHECK(hipStreamSynchronize(e->stream));
+    SYNC_ALL(e);
     e->mode[rx] = mode;
     HIPCHECK(hipMemcpy(e->d_mode + rx, &mode, sizeof(int), hipMemcpyHostToDevice));
     if (e->cls[rx] != cl) { e->cls[rx] = cl; return upload_members(e); }
@@ -1052,7 +1116,7 @@ int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int
     if (n >= 10001) return fail(QK_ERANGE, "Filter size must be less than 10001");       // quisk.c:4216-4219
     if (n > e->tap_cap)
         return fail(QK_ERANGE, "filter longer than the engine's tap capacity (qk_config.reserved[0])");
-    HIPCHECK(hipStreamSynchronize(e->stream));
+    SYNC_ALL(e);
     if (n > 0) {
         HIPCHECK(hipMemcpy(e->d_taps + (size_t)rx * 2 * e->tap_cap, fi, sizeof(double) * n, hipMemcpyHostToDevice));
         HIPCHECK(hipMemcpy(e->d_taps + (size_t)rx * 2 * e->tap_cap + e->tap_cap, fq, sizeof(double) * n, hipMemcpyHostToDevice));
@@ -1065,7 +1129,7 @@ int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int
 int qk_set_agc(qk_engine *e, int rx, double release_gain)
 {
     ENGINE_ENTER(e); RX_CHECK(e, rx);
-    HIPCHECK(hipStreamSynchronize(e->stream));
+    SYNC_ALL(e);
     HIPCHECK(hipMemcpy(e->d_release_gain + rx, &release_gain, sizeof(double), hipMemcpyHostToDevice));
     return QK_OK;
 }
@@ -1091,7 +1155,7 @@ int qk_process_samples(qk_engine *e, const double *iq_host, int n)
     if (n < 0 || n > e->cfg.max_block) return fail(QK_ERANGE, "block larger than max_block");
     if (!iq_host && n > 0) return fail(QK_EINVAL, "null sample pointer");
     if (n > 0) {
-        HIPCHECK(hipStreamSynchronize(e->stream));      // the previous block may still read d_in
+        SYNC_ALL(e);      // the previous block may still read d_in
         HIPCHECK(hipMemcpyAsync(e->d_in, iq_host, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, e->stream));
     }
     return process_device(e, e->d_in, n);
@@ -1105,7 +1169,7 @@ int qk_process_samples_int(qk_engine *e, const void *raw, size_t n_bytes, int by
     const size_t n = n_bytes / (2 * bytes);
     if (n > (size_t)e->cfg.max_block) return fail(QK_ERANGE, "buffer is too full");                       // quisk.c:2801
     if (n == 0) return process_device(e, e->d_in, 0);
-    HIPCHECK(hipStreamSynchronize(e->stream));
+    SYNC_ALL(e);
     if (n_bytes > e->raw_cap) {
         if (e->d_raw) hipFree(e->d_raw);
         e->raw_cap = (size_t)e->cfg.max_block * 8;
@@ -1120,7 +1184,7 @@ int qk_process_samples_int(qk_engine *e, const void *raw, size_t n_bytes, int by
 int qk_sync(qk_engine *e)
 {
     ENGINE_ENTER(e);
-    HIPCHECK(hipStreamSynchronize(e->stream));
+    SYNC_ALL(e);
     return QK_OK;
 }
 
@@ -1133,19 +1197,21 @@ int qk_audio_count(qk_engine *e, int rx)
 int qk_pull_audio(qk_engine *e, int rx, double *dst, int cap)
 {
     ENGINE_ENTER(e); RX_CHECK(e, rx);
+    HIPCHECK(hipStreamSynchronize(e->agc_stream));       // the AGC pass writes the audio output
     const int m = std::min(e->out_count[rx], cap);
     if (m > 0) {
         if (!dst) return fail(QK_EINVAL, "null destination");
         HIPCHECK(hipMemcpyAsync(dst, e->d_out + (size_t)rx * e->out_stride, (size_t)m * sizeof(double2),
                                 hipMemcpyDeviceToHost, e->stream));
     }
-    HIPCHECK(hipStreamSynchronize(e->stream));
+    SYNC_ALL(e);
     return m;
 }
 
 int qk_pull_audio_all(qk_engine *e, double *dst, size_t stride, int *counts)
 {
     ENGINE_ENTER(e);
+    HIPCHECK(hipStreamSynchronize(e->agc_stream));       // the AGC pass writes the audio output
     if (!dst || !counts) return fail(QK_EINVAL, "null destination");
     for (int r = 0; r < e->nrx; r++) {
         const int m = e->out_count[r];
@@ -1154,7 +1220,7 @@ int qk_pull_audio_all(qk_engine *e, double *dst, size_t stride, int *counts)
     }
     HIPCHECK(hipMemcpy2DAsync(dst, stride * sizeof(double2), e->d_out, e->out_stride * sizeof(double2),
                               std::min(stride, e->out_stride) * sizeof(double2), e->nrx, hipMemcpyDeviceToHost, e->stream));
-    HIPCHECK(hipStreamSynchronize(e->stream));
+    SYNC_ALL(e);
     return QK_OK;
 }
 
@@ -1210,6 +1276,7 @@ int qk_reset_stats(qk_engine *e)
 int qk_export_audio_device(qk_engine *e, double *dst_dev, size_t dst_stride)
 {
     ENGINE_ENTER(e);
+    HIPCHECK(hipStreamSynchronize(e->agc_stream));       // the AGC pass writes the audio output
     if (!dst_dev) return fail(QK_EINVAL, "null destination");
     size_t w = 0;
     for (int r = 0; r < e->nrx; r++) w = std::max(w, (size_t)e->out_count[r]);
@@ -1217,7 +1284,7 @@ int qk_export_audio_device(qk_engine *e, double *dst_dev, size_t dst_stride)
     if (w > 0)
         HIPCHECK(hipMemcpy2DAsync(dst_dev, dst_stride * sizeof(double2), e->d_out, e->out_stride * sizeof(double2),
                                   w * sizeof(double2), e->nrx, hipMemcpyDeviceToDevice, e->stream));
-    HIPCHECK(hipStreamSynchronize(e->stream));
+    SYNC_ALL(e);
     return QK_OK;
 }
 
@@ -1236,7 +1303,7 @@ int qk_debug_tap(qk_engine *e, int which, int rx, double *out, int cap)
     case QK_TAP_PLAY: if (c.built) s = &c.streams[c.play]; break;
     }
     if (!s || !s->d) return fail(QK_EINVAL, "no such tap");
-    HIPCHECK(hipStreamSynchronize(e->stream));
+    SYNC_ALL(e);
     const int m = std::min(s->n, cap);
     for (int p = 0; p < s->planes && m > 0; p++)
         HIPCHECK(hipMemcpy(out + (size_t)p * cap, s->d + (long long)rx * s->rx_stride() + (long long)p * (s->hist + s->cap) + s->hist,

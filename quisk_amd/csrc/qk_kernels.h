@@ -286,6 +286,218 @@ __global__ __launch_bounds__(FE_THREADS) void k_frontend(FrontArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Front end, wave-independent form (the one the engine launches).  Same arithmetic and LDS polyphase layout
+// as k_frontend above, but ONE WAVE owns a receiver x span and walks it in chunks of 384 samples (6 per
+// lane) with all its levels in its own 16 KiB of LDS: no workgroup barrier ever waits for another wave,
+// so a SIMD always has a runnable wave.  The deeper (smaller) stages use fewer outputs per lane,
+// R = 6, 3, 2, 1, 1, so that the 2 x 32 lanes (plane x item) stay busy; an idle lane costs a wave as much as
+// a busy one.
+// ------------------------------------------------------------------------------------------------
+#define FW_CHUNK 384
+struct FwLayout {
+    static __host__ __device__ constexpr int sub(int s) { return (FW_CHUNK >> (s + 1)) + FE_HIST + 14; }
+    static __host__ __device__ constexpr int level_off(int s) { int o = 0; for (int i = 0; i < s; i++) o += 4 * sub(i); return o; }
+    static __host__ __device__ constexpr int total(int S) { return level_off(S) + 16; }
+    static __host__ __device__ constexpr int R(int s) { return s == 0 ? 6 : s == 1 ? 3 : s == 2 ? 2 : 1; }
+    static __host__ __device__ constexpr int warm(int S) { return ((44 << S) + 63) / 64 * 64; }
+};
+__device__ __forceinline__ double *fw_arr(double *smem, int s, int plane, int phase)
+{
+    return smem + FwLayout::level_off(s) + (plane * 2 + phase) * FwLayout::sub(s);
+}
+
+template <int R>
+__device__ __forceinline__ void hb45_out(const double *__restrict__ O, const double *__restrict__ E, int m0, double (&y)[R])
+{
+    // o[j] = O[m0 + 2 + j] (odd-phase samples m0-21 .. m0+R-1), e[r] = E[m0 + 12 + r] (even-phase sample m0+r-10)
+    double o[R + 22];
+    double e[R + 1];
+    if constexpr (R % 2 == 0) {         // m0 even: 16-byte vector reads
+        const double2 *po = reinterpret_cast<const double2 *>(__builtin_assume_aligned(O, 16)) + (m0 / 2 + 1);
+#pragma unroll
+        for (int j = 0; j < (R + 22) / 2; j++) { const double2 v = po[j]; o[2 * j] = v.x; o[2 * j + 1] = v.y; }
+        const double2 *pe = reinterpret_cast<const double2 *>(__builtin_assume_aligned(E, 16)) + (m0 / 2 + 6);
+#pragma unroll
+        for (int j = 0; j < R / 2; j++) { const double2 v = pe[j]; e[2 * j] = v.x; e[2 * j + 1] = v.y; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < R + 21; j++) o[j] = O[m0 + 2 + j];
+#pragma unroll
+        for (int r = 0; r < R; r++) e[r] = E[m0 + 12 + r];
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        double acc = (o[r + 21] + o[r]) * HB_C0;
+        acc = fma(o[r + 20] + o[r + 1], HB_C1, acc);
+        acc = fma(o[r + 19] + o[r + 2], HB_C2, acc);
+        acc = fma(o[r + 18] + o[r + 3], HB_C3, acc);
+        acc = fma(o[r + 17] + o[r + 4], HB_C4, acc);
+        acc = fma(o[r + 16] + o[r + 5], HB_C5, acc);
+        acc = fma(o[r + 15] + o[r + 6], HB_C6, acc);
+        acc = fma(o[r + 14] + o[r + 7], HB_C7, acc);
+        acc = fma(o[r + 13] + o[r + 8], HB_C8, acc);
+        acc = fma(o[r + 12] + o[r + 9], HB_C9, acc);
+        acc = fma(o[r + 11] + o[r + 10], HB_C10, acc);
+        y[r] = fma(e[r], HB_C11, acc);
+    }
+}
+
+// carry the last 22 entries of the four polyphase arrays of level s to their front (88 doubles: lanes 0..43
+// move two each).  n_new = samples added per array this chunk.  One wave: every lane's reads are issued before
+// any lane's writes (same instruction stream, in-order LDS), so no barrier is needed even when they overlap.
+__device__ __forceinline__ void fw_carry(double *smem, int s, int n_new, int lane)
+{
+    if (lane < 44) {
+        const int sub = lane / 11, i = (lane % 11) * 2;         // 4 sub-arrays x 11 pairs
+        double *arr = smem + FwLayout::level_off(s) + sub * FwLayout::sub(s) + (sub & 1);
+        const double v0 = arr[n_new + i], v1 = arr[n_new + i + 1];
+        arr[i] = v0; arr[i + 1] = v1;
+    }
+}
+
+template <int S, int s>
+__device__ __forceinline__ void fw_stage(double *smem, int c, int lane, bool emit, double *out0, double *out1, long long obase)
+{
+    constexpr int R = FwLayout::R(s);
+    const int n_out = c >> (s + 1);
+    const int plane = lane >> 5, q = lane & 31;
+    const int m0 = q * R;
+    if (m0 < n_out) {
+        double y[R];
+        hb45_out<R>(fw_arr(smem, s, plane, 1), fw_arr(smem, s, plane, 0), m0, y);
+        if constexpr (s + 1 < S) {
+            double *En = fw_arr(smem, s + 1, plane, 0), *On = fw_arr(smem, s + 1, plane, 1);
+#pragma unroll
+            for (int r = 0; r < R; r++) {       // a partial last item spills into the arrays' padding
+                const int m = m0 + r;
+                double *d = (m & 1) ? On : En;
+                d[FE_HIST + (m & 1) + (m >> 1)] = y[r];
+            }
+        } else {
+            if (emit) {
+                double *op = (plane ? out1 : out0) + obase + m0;
+                if (m0 + R <= n_out) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) op[r] = y[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        if (m0 + r < n_out) op[r] = y[r];
+                }
+            }
+        }
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double smem[FwLayout::total(S)];
+    const int rx = blockIdx.y, lane = threadIdx.x;
+    const long long g_lo = a.g_lo0 + (long long)blockIdx.x * a.span_len;
+    if (g_lo >= a.g_end) return;
+    const long long g_hi = (g_lo + a.span_len < a.g_end) ? g_lo + a.span_len : a.g_end;
+    constexpr int W = FwLayout::warm(S);
+    constexpr int NIT = FW_CHUNK / 64;
+    for (int i = lane; i < FwLayout::level_off(S); i += 64) smem[i] = 0.0;
+    const int mix = a.mt.mix_on[rx];
+    const double2 *histp = a.hist + (long long)rx * a.H;
+    double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
+    long long pos = g_lo - W;
+    double *E0 = fw_arr(smem, 0, 0, 0), *O0 = fw_arr(smem, 0, 0, 1);
+    double *E1 = fw_arr(smem, 0, 1, 0), *O1 = fw_arr(smem, 0, 1, 1);
+    // a lane's six samples of a chunk have the same parity as the lane
+    double *d0 = (lane & 1) ? O0 : E0, *d1 = (lane & 1) ? O1 : E1;
+    const int dofs = FE_HIST + (lane & 1) + (lane >> 1);
+    // The lane's mixer phasor: exact (from the tables) at its first in-block sample, then advanced by phase^64
+    // from sample to sample of the lane (64 apart).  The recurrence runs over one span only (a few hundred
+    // steps, ~1e-14 of rounding), then the next span starts from the tables again.
+    const double2 P64 = a.mt.tabB[rx * 64 + 1];
+    double2 w = make_double2(1.0, 0.0);
+    {
+        long long kf = pos - a.N0 + lane;                // block-relative index of the lane's first sample
+        if (kf < 0) kf += ((-kf + 63) >> 6) << 6;        // first one inside this block (same lane)
+        if (mix) w = mix_w(a.mt, rx, kf);
+    }
+    // prefetch of the first chunk
+    double2 xv[NIT];
+    auto fetch = [&](long long p, int c) {
+        const long long k0 = p - a.N0;
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = lane + 64 * it;
+            const long long k = k0 + i;
+            xv[it] = make_double2(0.0, 0.0);
+            if (i < c) {
+                if (k >= 0) xv[it] = a.x[k];
+                else { const long long hi = k + a.H; if (hi >= 0) xv[it] = histp[hi]; }
+            }
+        }
+    };
+    auto chunk_len = [&](long long p) -> int {
+        const long long lim = (p >= g_lo) ? g_hi : g_lo;
+        return (lim - p < FW_CHUNK) ? (int)(lim - p) : FW_CHUNK;
+    };
+    int c = chunk_len(pos);
+    fetch(pos, c);
+    __syncthreads();
+    while (pos < g_hi) {
+        const bool emit = pos >= g_lo;
+        const long long k0 = pos - a.N0;
+        // ---- mix the prefetched samples into level 0 ----
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = lane + 64 * it;
+            if (i < c) {
+                double2 v = xv[it];
+                if (k0 + i >= 0 && mix) { v = cmul(v, w); w = cmul(w, P64); }
+                d0[dofs + 32 * it] = v.x; d1[dofs + 32 * it] = v.y;
+            }
+        }
+        // ---- next chunk's samples start their trip now ----
+        const long long npos = pos + c;
+        const int nc = npos < g_hi ? chunk_len(npos) : 0;
+        if (nc > 0) fetch(npos, nc);
+        __syncthreads();
+        const long long obase = (pos >> S) - a.J0;
+        const bool full = c == FW_CHUNK;                 // partial chunks (warm-up tail, span end) take the safe path
+        fw_stage<S, 0>(smem, c, lane, emit, out0, out1, obase);
+        __syncthreads();
+        if (full) fw_carry(smem, 0, c >> 1, lane);
+        if constexpr (S > 1) { fw_stage<S, 1>(smem, c, lane, emit, out0, out1, obase); __syncthreads(); if (full) fw_carry(smem, 1, c >> 2, lane); }
+        if constexpr (S > 2) { fw_stage<S, 2>(smem, c, lane, emit, out0, out1, obase); __syncthreads(); if (full) fw_carry(smem, 2, c >> 3, lane); }
+        if constexpr (S > 3) { fw_stage<S, 3>(smem, c, lane, emit, out0, out1, obase); __syncthreads(); if (full) fw_carry(smem, 3, c >> 4, lane); }
+        if constexpr (S > 4) { fw_stage<S, 4>(smem, c, lane, emit, out0, out1, obase); __syncthreads(); if (full) fw_carry(smem, 4, c >> 5, lane); }
+        if (!full) {
+            // generic carry with a barrier between the reads and the writes (source and destination may overlap)
+            constexpr int NC = S * 4 * FE_HIST;
+            double keep[(NC + 63) / 64];
+#pragma unroll
+            for (int u = 0; u < (NC + 63) / 64; u++) {
+                const int wi = lane + 64 * u;
+                if (wi < NC) {
+                    const int s = wi / (4 * FE_HIST), rem = wi % (4 * FE_HIST);
+                    const int sub = rem / FE_HIST, i = rem % FE_HIST;
+                    keep[u] = fw_arr(smem, s, sub >> 1, sub & 1)[(c >> (s + 1)) + (sub & 1) + i];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < (NC + 63) / 64; u++) {
+                const int wi = lane + 64 * u;
+                if (wi < NC) {
+                    const int s = wi / (4 * FE_HIST), rem = wi % (4 * FE_HIST);
+                    const int sub = rem / FE_HIST, i = rem % FE_HIST;
+                    fw_arr(smem, s, sub >> 1, sub & 1)[(sub & 1) + i] = keep[u];
+                }
+            }
+        }
+        __syncthreads();
+        pos = npos; c = nc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Generic real-coefficient FIR with decimation on a planar stream: quisk_cDecimate / quisk_dDecimate /
 // quisk_dFilter / quisk_cFilter (filter.c:180-206, 236-262, 324-352).  Output j uses the newest input at
 // index first + D j and accumulates h[k] x[newest - k] for k = 0..T-1 in the reference's order.
@@ -673,7 +885,7 @@ __global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
 // End of block: move the last `hist` samples of every stream to the front of its buffer.
 // ------------------------------------------------------------------------------------------------
 #define QK_MAX_TAILS 24
-struct TailDesc { double *d; long long rx_stride; int plane_stride, planes, hist, n; };
+struct TailDesc { double *d; long long rx_stride; int plane_stride, planes, hist, n; double *dst; };   // dst: same layout (ping-pong twin) or d itself
 struct TailArgs { TailDesc t[QK_MAX_TAILS]; int count; const int *rx_list; };
 __global__ __launch_bounds__(256) void k_save_tails(TailArgs a)
 {
@@ -681,14 +893,16 @@ __global__ __launch_bounds__(256) void k_save_tails(TailArgs a)
     const TailDesc td = a.t[blockIdx.x];
     if ((int)blockIdx.y >= td.planes || td.n <= 0) return;
     const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
-    double *base = td.d + (long long)rx * td.rx_stride + (long long)blockIdx.y * td.plane_stride;
+    const long long off = (long long)rx * td.rx_stride + (long long)blockIdx.y * td.plane_stride;
+    const double *base = td.d + off;
+    double *dbase = td.dst + off;
     // dest[i] = src[i + n], i in [0, hist); ascending chunks keep reads ahead of writes when n < hist
     for (int c0 = 0; c0 < td.hist; c0 += 256) {
         const int i = c0 + threadIdx.x;
         double v = 0.0;
         if (i < td.hist) v = base[i + td.n];
         __syncthreads();
-        if (i < td.hist) base[i] = v;
+        if (i < td.hist) dbase[i] = v;
         __syncthreads();
     }
 }
