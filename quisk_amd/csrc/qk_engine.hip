@@ -1311,9 +1311,41 @@ int qk_debug_tap(qk_engine *e, int which, int rx, double *out, int cap)
     return m;
 }
 
-int quisk_cCplxSampleFilter(double *, int, const double *, int, int, double *, int *)
-{ return fail(QK_EUNSUPPORTED, "not implemented yet"); }
-int quisk_ccfFilter(double *, int, const double *, int, int, double *, int *)
-{ return fail(QK_EUNSUPPORTED, "not implemented yet"); }
+static int fir_dropin(double *samples, int count, const double *coefs, int ntaps, int decim, double *hist, int *phase, int cpx)
+{
+    if (!samples || !coefs || !hist || !phase || count < 0 || ntaps < 1 || decim < 1 || *phase < 0 || *phase >= decim)
+        return fail(QK_EINVAL, "bad FIR arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(QK_EHIP, "no HIP device: the engine has no CPU path");
+    const int n_out = (*phase + count) / decim, first = decim - 1 - *phase;
+    const size_t nh = (size_t)ntaps - 1, ntot = nh + (size_t)count;
+    double2 *dx = nullptr, *dy = nullptr; double *dh = nullptr;
+    auto cleanup = [&]() { if (dx) hipFree(dx); if (dy) hipFree(dy); if (dh) hipFree(dh); };
+#define DROPCHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(QK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+    DROPCHECK(hipMalloc(&dx, std::max<size_t>(ntot, 1) * sizeof(double2)));
+    DROPCHECK(hipMalloc(&dy, std::max<size_t>(n_out, 1) * sizeof(double2)));
+    DROPCHECK(hipMalloc(&dh, (size_t)ntaps * (cpx ? 2 : 1) * sizeof(double)));
+    if (nh) DROPCHECK(hipMemcpy(dx, hist, nh * sizeof(double2), hipMemcpyHostToDevice));
+    if (count) DROPCHECK(hipMemcpy(dx + nh, samples, (size_t)count * sizeof(double2), hipMemcpyHostToDevice));
+    DROPCHECK(hipMemcpy(dh, coefs, (size_t)ntaps * (cpx ? 2 : 1) * sizeof(double), hipMemcpyHostToDevice));
+    if (n_out > 0) {
+        hipLaunchKernelGGL(k_cfir_interleaved, dim3((n_out + 255) / 256), dim3(256), 0, 0, dx, dy, dh, ntaps, decim, first, n_out, cpx);
+        DROPCHECK(hipGetLastError());
+    }
+    // new history = the last ntaps-1 samples of (old history + block); read before the outputs overwrite `samples`
+    std::vector<double> nhist(2 * nh);
+    if (nh) DROPCHECK(hipMemcpy(nhist.data(), dx + (ntot - nh), nh * sizeof(double2), hipMemcpyDeviceToHost));
+    if (n_out > 0) DROPCHECK(hipMemcpy(samples, dy, (size_t)n_out * sizeof(double2), hipMemcpyDeviceToHost));
+#undef DROPCHECK
+    if (nh) memcpy(hist, nhist.data(), nh * sizeof(double2));
+    *phase = (*phase + count) % decim;
+    cleanup();
+    return n_out;
+}
+
+int quisk_cCplxSampleFilter(double *samples, int count, const double *coefs, int ntaps, int decim, double *hist, int *phase)
+{ return fir_dropin(samples, count, coefs, ntaps, decim, hist, phase, 0); }
+int quisk_ccfFilter(double *samples, int count, const double *cpx_coefs, int ntaps, int decim, double *hist, int *phase)
+{ return fir_dropin(samples, count, cpx_coefs, ntaps, decim, hist, phase, 1); }
 
 }  // extern "C"

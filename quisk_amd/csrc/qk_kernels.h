@@ -925,3 +925,31 @@ __global__ __launch_bounds__(256) void k_unpack_int(const unsigned char *raw, do
     }
     out[i] = make_double2((double)v[0], (double)v[1]);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone FIR over interleaved complex samples for the filter.c drop-ins (quisk_cDecimate, filter.c:180-206;
+// quisk_cCDecimate, filter.c:208-234).  x holds ntaps-1 history samples followed by the new block.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cfir_interleaved(const double2 *x, double2 *y, const double *h, int T, int D,
+                                                          int first, int n_out, int cpx)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_out) return;
+    const double2 *p = x + (T - 1) + first + (long long)D * j;      // newest sample of output j
+    double ar = 0.0, ai = 0.0;
+    if (cpx) {
+        const double2 *c = reinterpret_cast<const double2 *>(h);
+        for (int k = 0; k < T; k++) {
+            const double2 v = p[-k], w = c[k];
+            ar += v.x * w.x - v.y * w.y;
+            ai += v.x * w.y + v.y * w.x;
+        }
+    } else {
+        for (int k = 0; k < T; k++) {
+            const double2 v = p[-k];
+            ar = fma(v.x, h[k], ar);
+            ai = fma(v.y, h[k], ai);
+        }
+    }
+    y[j] = make_double2(ar, ai);
+}
