@@ -131,6 +131,8 @@ int qk_reset_stats(qk_engine *e);
  * which: QK_TAP_*; out: [planes][count] doubles; returns count per plane. */
 enum { QK_TAP_FRONTEND = 0, QK_TAP_DECIM = 1, QK_TAP_DEMOD = 2, QK_TAP_AUDIO48 = 3, QK_TAP_PLAY = 4 };
 int qk_debug_tap(qk_engine *e, int which, int rx, double *out_host, int cap);
+/* Statistics (debug): speculation passes the AGC kernel has run for receiver rx since creation. */
+long long qk_debug_agc_passes(qk_engine *e, int rx);
 
 /* filter.c drop-ins (filter.h:39-54) for callers that hold their samples in host memory.  The two names
  * BASELINE.json's north_star uses for them come from later Quisk releases and do not exist in this

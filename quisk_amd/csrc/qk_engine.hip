@@ -1343,6 +1343,17 @@ static int fir_dropin(double *samples, int count, const double *coefs, int ntaps
     return n_out;
 }
 
+long long qk_debug_agc_passes(qk_engine *e, int rx)
+{   /* statistics: speculation passes the AGC kernel has run for this receiver (debug) */
+    if (!e || rx < 0 || rx >= e->nrx) return -1;
+    std::lock_guard<std::mutex> lk(e->mu);
+    hipSetDevice(e->cfg.device);
+    hipStreamSynchronize(e->stream); hipStreamSynchronize(e->agc_stream);
+    AgcState st;
+    if (hipMemcpy(&st, e->d_agc + rx, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return st.pad;
+}
+
 int quisk_cCplxSampleFilter(double *samples, int count, const double *coefs, int ntaps, int decim, double *hist, int *phase)
 { return fir_dropin(samples, count, coefs, ntaps, decim, hist, phase, 0); }
 int quisk_ccfFilter(double *samples, int count, const double *cpx_coefs, int ntaps, int decim, double *hist, int *phase)

@@ -804,7 +804,6 @@ __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
     c.bs = (double)a.buf_size; c.buf_size = a.buf_size;
     const int md = a.mode[rx];
     c.fm = (md == 5 || md == 13);
-    __shared__ double sg[72];         // gain in force at each sample of the tile, [64] = gain after the tile
     double mv = (lane < a.n) ? fabs(p[lane]) : 0.0;
     for (int i0 = 0; i0 < a.n; i0 += 64) {
         const int nxt = i0 + 64 + lane;
@@ -813,32 +812,31 @@ __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
         double gv = 0.0;                                               // gain in force at this lane's sample
         int start = 0;
         while (start < cnt) {
+            s.pad++;                                                    // statistics: speculation passes
             double gcur = s.gain;
             const bool mine = lane >= start && lane < cnt;
             bool ev;
             if (!s.is_clipping) {
                 const double tt = s.target_gain * c.tr;
-                if (lane == 0) {                                       // the serial part: 2 flops per sample
-                    double gc = gcur;
-#pragma unroll 8
-                    for (int j = start; j < cnt; j++) { sg[j] = gc; gc = gc * c.keep + tt; }
-                    sg[64] = gc;
+                // the serial part: 2 dependent flops per sample, computed by every lane alike (wave-uniform);
+                // lane j keeps the value in force at sample j.  The selects are off the dependent chain.
+                if (start == 0 && cnt == 64) {
+#pragma unroll
+                    for (int j = 0; j < 64; j++) { if (lane == j) gv = gcur; gcur = gcur * c.keep + tt; }
+                } else {
+                    for (int j = start; j < cnt; j++) { if (lane == j) gv = gcur; gcur = gcur * c.keep + tt; }
                 }
-                if (lane >= start) gv = sg[lane];
-                gcur = sg[64];
                 int idx = s.index_read + (lane - start);               // buf_size >= 720 > 64: one wrap at most
                 if (idx >= a.buf_size) idx -= a.buf_size;
                 ev = mine && ((mv * gv > c.ceil_) || (idx == s.index_start));
             } else {
                 const double dl = s.delta;
-                if (lane == 0) {
-                    double gc = gcur;
-#pragma unroll 8
-                    for (int j = start; j < cnt; j++) { sg[j] = gc; gc = gc - dl; }
-                    sg[64] = gc;
+                if (start == 0 && cnt == 64) {
+#pragma unroll
+                    for (int j = 0; j < 64; j++) { if (lane == j) gv = gcur; gcur = gcur - dl; }
+                } else {
+                    for (int j = start; j < cnt; j++) { if (lane == j) gv = gcur; gcur = gcur - dl; }
                 }
-                if (lane >= start) gv = sg[lane];
-                gcur = sg[64];
                 ev = mine && ((mv > s.themax) || (gv - dl <= s.target_gain));
             }
             const unsigned long long mask = __ballot(ev);
