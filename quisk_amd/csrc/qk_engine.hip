@@ -49,8 +49,8 @@ struct Stream {
 struct Stage {
     StageKind kind;
     int in, out;               // stream indices within the owning chain (in == -1: the chain's input stream)
-    const double *h = nullptr; // device taps
-    int T = 0, D = 1, L = 1;
+    const double *h = nullptr; // device taps (ST_FIR: permuted [D][TQP], see fir_tile)
+    int T = 0, D = 1, L = 1, TQP = 0;
     int phase = 0;             // decimation counter / resampler index carried between blocks
     int rxf_kind = 0, iir_kind = 0;
     double a0 = 0, a1 = 0, b1 = 0, fs = 0;
@@ -75,6 +75,8 @@ struct Chain {
 };
 
 struct DevTables { std::vector<double> host; double *dev = nullptr; };
+struct FirTab { const double *hp = nullptr; int T = 0, D = 1, TQP = 0; };     // decimating FIR: permuted taps on the device
+constexpr int FT_NTH = 128, FT_R = 5;      // k_fir_tiled / k_rxf_tiled: lanes per workgroup, outputs per lane
 
 }  // namespace
 
@@ -103,9 +105,8 @@ struct qk_engine {
     std::vector<int> tune, mode, cls;
     // coefficient tables
     double *d_coefs = nullptr;
-    const double *h_dec2 = nullptr, *h_dec3 = nullptr, *h_dec5 = nullptr, *h_rs65 = nullptr, *h_hbdec = nullptr,
-                 *h_s53 = nullptr, *h_s111 = nullptr, *h_s133 = nullptr, *h_s167 = nullptr, *h_s185 = nullptr,
-                 *h_a24p3 = nullptr, *h_a24p4 = nullptr, *h_a24p6 = nullptr, *h_fmhp = nullptr;
+    const double *h_dec5 = nullptr, *h_rs65 = nullptr, *h_a24p4 = nullptr;      // raw tables (resampler, interpolator)
+    FirTab f_dec2, f_dec3, f_dec5, f_hbdec, f_s53, f_s111, f_s133, f_s167, f_s185, f_a24p3, f_a24p6, f_fmhp;
     // front chain (shared by all receivers): stream 0 = front-end output
     Chain front;
     Chain cls_chain[CL_COUNT];
@@ -231,11 +232,11 @@ struct ChainBuilder {
         cur = st.out; cur_cap = cap_out;
         return c.stages.back();
     }
-    void fir(const double *h, int T, int D, int planes, int timer)
+    void fir(const FirTab &f, int planes, int timer)
     {
-        need_hist(cur, T - 1);
-        Stage &s = add(ST_FIR, planes, cur_cap / D + 2);
-        s.h = h; s.T = T; s.D = D; s.timer = timer;
+        need_hist(cur, f.D * f.TQP + f.D);      // the tiled kernel reads whole tap chunks (zero-padded taps)
+        Stage &s = add(ST_FIR, planes, cur_cap / f.D + 2);
+        s.h = f.hp; s.T = f.T; s.D = f.D; s.TQP = f.TQP; s.timer = timer;
     }
     void interp(const double *h, int T, int L, int timer)
     {
@@ -290,24 +291,23 @@ static int build_front(qk_engine *e)
     e->rate_case = rate_case_of(rate);
     Chain &c = e->front;
     int S = 0;
-    struct Fir { const double *h; int T, D; };
-    std::vector<Fir> firs;
+    std::vector<const FirTab *> firs;
     bool resample = false;
     switch (e->rate_case) {
     case 41: break;
-    case 53: firs.push_back({e->h_s53, 55, 1}); break;
-    case 111: firs.push_back({e->h_s111, 114, 2}); break;
-    case 133: firs.push_back({e->h_s133, 136, 2}); break;
-    case 185: firs.push_back({e->h_s185, 189, 3}); break;
-    case 370: S = 1; firs.push_back({e->h_s185, 189, 3}); break;
-    case 740: S = 2; firs.push_back({e->h_s185, 189, 3}); break;
-    case 1333: S = 3; firs.push_back({e->h_s167, 174, 3}); break;
+    case 53: firs.push_back(&e->f_s53); break;
+    case 111: firs.push_back(&e->f_s111); break;
+    case 133: firs.push_back(&e->f_s133); break;
+    case 185: firs.push_back(&e->f_s185); break;
+    case 370: S = 1; firs.push_back(&e->f_s185); break;
+    case 740: S = 2; firs.push_back(&e->f_s185); break;
+    case 1333: S = 3; firs.push_back(&e->f_s167); break;
     default: {
         plan_decimation(rate, &d2, &d3, &d5);
         S = std::min(std::max(d2 - 1, 0), 5);
-        for (int i = 0; i < d3; i++) firs.push_back({e->h_dec3, 147, 3});
-        for (int i = 0; i < d5; i++) firs.push_back({e->h_dec5, 245, 5});
-        if (d2 > 0) firs.push_back({e->h_dec2, 98, 2});
+        for (int i = 0; i < d3; i++) firs.push_back(&e->f_dec3);
+        for (int i = 0; i < d5; i++) firs.push_back(&e->f_dec5);
+        if (d2 > 0) firs.push_back(&e->f_dec2);
         int r = rate;
         for (int i = 0; i < d2; i++) r /= 2;
         for (int i = 0; i < d3; i++) r /= 3;
@@ -325,7 +325,7 @@ static int build_front(qk_engine *e)
     // stream 0: front-end output (mixer + S half-bands)
     b.cur = b.new_stream(2, (e->cfg.max_block >> S) + 2);
     b.cur_cap = (e->cfg.max_block >> S) + 2;
-    for (auto &f : firs) b.fir(f.h, f.T, f.D, 2, QK_KT_DECIM);
+    for (auto *f : firs) b.fir(*f, 2, QK_KT_DECIM);
     if (resample) {
         b.resamp(e->h_rs65, 125, 6, 5, QK_KT_DECIM);
         b.resamp(e->h_dec5, 245, 4, 5, QK_KT_DECIM);
@@ -342,7 +342,7 @@ static int build_class(qk_engine *e, int cl)
     ChainBuilder b(c, dec.cap);
     const int T_A = QK_KT_DEMOD, T_B = QK_KT_AUDIO;
     auto rxf = [&](int kind, int planes_out) {
-        b.need_hist(b.cur, e->tap_cap);
+        b.need_hist(b.cur, e->tap_cap + FT_QB);
         Stage &s = b.add(ST_RXF, planes_out, b.cur_cap + 2);
         s.rxf_kind = kind; s.timer = T_A;
     };
@@ -360,26 +360,26 @@ static int build_class(qk_engine *e, int cl)
     int rc = QK_OK;
     switch (cl) {
     case CL_SSB:    // quisk.c:1817-1862
-        b.fir(e->h_hbdec, 43, 2, 2, T_A);
-        b.fir(e->h_dec2, 98, 2, 2, T_A);
+        b.fir(e->f_hbdec, 2, T_A);
+        b.fir(e->f_dec2, 2, T_A);
         rxf(0, 1);
         b.interp(e->h_a24p4, 50, 2, T_B);
         b.hbint(1, T_B);
         break;
     case CL_CW:     // quisk.c:1779-1816
-        b.fir(e->h_hbdec, 43, 2, 2, T_A);
-        b.fir(e->h_hbdec, 43, 2, 2, T_A);
-        b.fir(e->h_dec2, 98, 2, 2, T_A);
+        b.fir(e->f_hbdec, 2, T_A);
+        b.fir(e->f_hbdec, 2, T_A);
+        b.fir(e->f_dec2, 2, T_A);
         rxf(0, 1);
         b.interp(e->h_a24p4, 50, 2, T_B);
         b.hbint(1, T_B);
         b.hbint(1, T_B);
         break;
     case CL_AM:     // quisk.c:1863-1886
-        b.fir(e->h_dec2, 98, 2, 2, T_A);
+        b.fir(e->f_dec2, 2, T_A);
         rxf(1, 1);
         rc = iir(0);
-        b.fir(e->h_a24p6, 36, 1, 1, T_B);
+        b.fir(e->f_a24p6, 1, T_B);
         b.hbint(1, T_B);
         break;
     case CL_FM: {   // quisk.c:1887-1921
@@ -388,8 +388,8 @@ static int build_class(qk_engine *e, int cl)
         Stage &s = b.add(ST_FMDISC, 1, b.cur_cap + 2);
         s.fs = e->decim_srate; s.timer = T_A;
         rc = iir(1);
-        b.fir(e->h_a24p3, 100, 2, 1, T_B);
-        b.fir(e->h_fmhp, 309, 1, 1, T_B);
+        b.fir(e->f_a24p3, 1, T_B);
+        b.fir(e->f_fmhp, 1, T_B);
         b.hbint(1, T_B);
         break;
     }
@@ -475,6 +475,19 @@ static const double *push_table(DevTables &t, const double *src, int n)
     return reinterpret_cast<const double *>(off);      // offset, turned into a pointer after upload
 }
 
+// taps of a decimate-by-D FIR in the layout fir_tile reads: hp[p][q] = h[p + D q], zero-padded to TQP per branch
+static FirTab push_fir(DevTables &t, const double *src, int n, int D)
+{
+    FirTab f; f.T = n; f.D = D;
+    const int TQ = (n + D - 1) / D;
+    f.TQP = (TQ + FT_QB - 1) / FT_QB * FT_QB;
+    size_t off = t.host.size();
+    t.host.resize(off + (size_t)D * f.TQP, 0.0);
+    for (int k = 0; k < n; k++) t.host[off + (size_t)(k % D) * f.TQP + k / D] = src[k];
+    f.hp = reinterpret_cast<const double *>(off);
+    return f;
+}
+
 static int init_spectrum(qk_engine *e);
 
 static int init_receivers(qk_engine *e)
@@ -548,7 +561,7 @@ static int init_receivers(qk_engine *e)
     // (the receive band-pass of the FM class reads it directly; the others put a 98-tap FIR first).
     {
         Stream &dec = e->front.streams[e->front.aud];
-        dec.hist = std::max(dec.hist, (std::max(e->tap_cap, 98) + 1) & ~1);
+        dec.hist = std::max(dec.hist, std::max(e->tap_cap + FT_QB, 2 * 56 + 2));
     }
     rc = alloc_chain_streams(e, e->front);
     if (rc != QK_OK) return rc;
@@ -573,19 +586,21 @@ static int engine_init(qk_engine *e)
     static const double c12[12] = { HB_C0, HB_C1, HB_C2, HB_C3, HB_C4, HB_C5, HB_C6, HB_C7, HB_C8, HB_C9, HB_C10, HB_C11 };
     for (int k = 0; k < 11; k++) { hb43[2 * k] = c12[k]; hb43[42 - 2 * k] = c12[k]; }
     hb43[21] = c12[11];
-    const double *o_dec2 = push_table(T, qk_h_dec2_98, 98), *o_dec3 = push_table(T, qk_h_dec3_147, 147),
-                 *o_dec5 = push_table(T, qk_h_dec5_245, 245), *o_rs65 = push_table(T, qk_h_rs65_125, 125),
-                 *o_hb = push_table(T, hb43, 43), *o_s53 = push_table(T, qk_h_sdriq53_55, 55),
-                 *o_s111 = push_table(T, qk_h_sdriq111_114, 114), *o_s133 = push_table(T, qk_h_sdriq133_136, 136),
-                 *o_s167 = push_table(T, qk_h_sdriq167_174, 174), *o_s185 = push_table(T, qk_h_sdriq185_189, 189),
-                 *o_a3 = push_table(T, qk_h_aud24p3_100, 100), *o_a4 = push_table(T, qk_h_aud24p4_50, 50),
-                 *o_a6 = push_table(T, qk_h_aud24p6_36, 36), *o_fm = push_table(T, qk_h_fmhp_309, 309);
+    const double *o_dec5 = push_table(T, qk_h_dec5_245, 245), *o_rs65 = push_table(T, qk_h_rs65_125, 125),
+                 *o_a4 = push_table(T, qk_h_aud24p4_50, 50);
+    e->f_dec2 = push_fir(T, qk_h_dec2_98, 98, 2);        e->f_dec3 = push_fir(T, qk_h_dec3_147, 147, 3);
+    e->f_dec5 = push_fir(T, qk_h_dec5_245, 245, 5);      e->f_hbdec = push_fir(T, hb43, 43, 2);
+    e->f_s53 = push_fir(T, qk_h_sdriq53_55, 55, 1);      e->f_s111 = push_fir(T, qk_h_sdriq111_114, 114, 2);
+    e->f_s133 = push_fir(T, qk_h_sdriq133_136, 136, 2);  e->f_s167 = push_fir(T, qk_h_sdriq167_174, 174, 3);
+    e->f_s185 = push_fir(T, qk_h_sdriq185_189, 189, 3);  e->f_a24p3 = push_fir(T, qk_h_aud24p3_100, 100, 2);
+    e->f_a24p6 = push_fir(T, qk_h_aud24p6_36, 36, 1);    e->f_fmhp = push_fir(T, qk_h_fmhp_309, 309, 1);
     HIPCHECK(hipMalloc(&e->d_coefs, T.host.size() * sizeof(double)));
     HIPCHECK(hipMemcpy(e->d_coefs, T.host.data(), T.host.size() * sizeof(double), hipMemcpyHostToDevice));
 #define FIX(dst, off) e->dst = e->d_coefs + reinterpret_cast<size_t>(off)
-    FIX(h_dec2, o_dec2); FIX(h_dec3, o_dec3); FIX(h_dec5, o_dec5); FIX(h_rs65, o_rs65); FIX(h_hbdec, o_hb);
-    FIX(h_s53, o_s53); FIX(h_s111, o_s111); FIX(h_s133, o_s133); FIX(h_s167, o_s167); FIX(h_s185, o_s185);
-    FIX(h_a24p3, o_a3); FIX(h_a24p4, o_a4); FIX(h_a24p6, o_a6); FIX(h_fmhp, o_fm);
+    FIX(h_dec5, o_dec5); FIX(h_rs65, o_rs65); FIX(h_a24p4, o_a4);
+    for (FirTab *f : {&e->f_dec2, &e->f_dec3, &e->f_dec5, &e->f_hbdec, &e->f_s53, &e->f_s111, &e->f_s133, &e->f_s167,
+                      &e->f_s185, &e->f_a24p3, &e->f_a24p6, &e->f_fmhp})
+        f->hp = e->d_coefs + reinterpret_cast<size_t>(f->hp);
 #undef FIX
     int rc = QK_OK;
     HIPCHECK(hipMalloc(&e->d_in, (size_t)cfg.max_block * sizeof(double2)));
@@ -780,9 +795,17 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             st.phase = (st.phase + n_in) % st.D;
             out.n = n_out;
             if (n_out > 0) {
-                FirArgs a{in.view(), out.view(), st.h, st.T, st.D, first, n_out, d_list, 0};
+                FirTArgs a{in.view(), out.view(), st.h, st.TQP, first, n_out, d_list};
                 Timer tm(e, st.timer);
-                hipLaunchKernelGGL(k_fir_decim, grid1(n_out, in.planes, nlist), dim3(256), 0, e->stream, a);
+                const dim3 grid((n_out + FT_NTH * FT_R - 1) / (FT_NTH * FT_R), in.planes, nlist);
+                const size_t lds = sizeof(double) * st.D * (FT_NTH * FT_R + st.TQP);
+                switch (st.D) {
+                case 1: hipLaunchKernelGGL((k_fir_tiled<1, FT_NTH, FT_R>), grid, dim3(FT_NTH), lds, e->stream, a); break;
+                case 2: hipLaunchKernelGGL((k_fir_tiled<2, FT_NTH, FT_R>), grid, dim3(FT_NTH), lds, e->stream, a); break;
+                case 3: hipLaunchKernelGGL((k_fir_tiled<3, FT_NTH, FT_R>), grid, dim3(FT_NTH), lds, e->stream, a); break;
+                case 5: hipLaunchKernelGGL((k_fir_tiled<5, FT_NTH, FT_R>), grid, dim3(FT_NTH), lds, e->stream, a); break;
+                default: return fail(QK_EINVAL, "internal: FIR decimation factor without a kernel");
+                }
             }
             break;
         }
@@ -822,7 +845,11 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             if (n_in > 0) {
                 RxfArgs a{in.view(), out.view(), e->d_taps, e->d_ntaps, e->d_mode, e->tap_cap, n_in, st.rxf_kind, d_list};
                 Timer tm(e, st.timer);
-                hipLaunchKernelGGL(k_rxfilter, grid1(n_in, 1, nlist), dim3(256), 0, e->stream, a);
+                int nmax = 0;
+                for (int r : c.members) nmax = std::max(nmax, e->ntaps[r]);
+                const int tqp = std::max(FT_QB, (nmax + FT_QB - 1) / FT_QB * FT_QB);
+                const dim3 grid((n_in + FT_NTH * FT_R - 1) / (FT_NTH * FT_R), 1, nlist);
+                hipLaunchKernelGGL((k_rxf_tiled<FT_NTH, FT_R>), grid, dim3(FT_NTH), sizeof(double) * (FT_NTH * FT_R + tqp), e->stream, a);
             }
             break;
         }
@@ -1051,7 +1078,7 @@ int qk_create(qk_engine **out, const qk_config *cfg)
     qk_engine *e = new (std::nothrow) qk_engine();
     if (!e) return fail(QK_ENOMEM, "out of host memory");
     e->cfg = *cfg;
-    if (cfg->reserved[0] > 0) e->tap_cap = (cfg->reserved[0] + 1) & ~1;   // max receive-filter taps
+    if (cfg->reserved[0] > 0) e->tap_cap = (cfg->reserved[0] + FT_QB - 1) / FT_QB * FT_QB;   // max receive-filter taps
     int rc = engine_init(e);
     if (rc != QK_OK) { std::string keep = g_err; qk_destroy(e); g_err = keep; return rc; }
     *out = e;
@@ -1117,9 +1144,13 @@ int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int
     if (n > e->tap_cap)
         return fail(QK_ERANGE, "filter longer than the engine's tap capacity (qk_config.reserved[0])");
     SYNC_ALL(e);
-    if (n > 0) {
-        HIPCHECK(hipMemcpy(e->d_taps + (size_t)rx * 2 * e->tap_cap, fi, sizeof(double) * n, hipMemcpyHostToDevice));
-        HIPCHECK(hipMemcpy(e->d_taps + (size_t)rx * 2 * e->tap_cap + e->tap_cap, fq, sizeof(double) * n, hipMemcpyHostToDevice));
+    {   // the tap order of cRxFilterOut (quisk.c:1176-1186) as a plain FIR: h[0] = f[0], h[m] = f[n - m]; zero-padded
+        std::vector<double> hp((size_t)2 * e->tap_cap, 0.0);
+        for (int m = 0; m < n; m++) {
+            hp[m] = fi[m ? n - m : 0];
+            hp[(size_t)e->tap_cap + m] = fq[m ? n - m : 0];
+        }
+        HIPCHECK(hipMemcpy(e->d_taps + (size_t)rx * 2 * e->tap_cap, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
     }
     HIPCHECK(hipMemcpy(e->d_ntaps + rx, &n, sizeof(int), hipMemcpyHostToDevice));
     e->ntaps[rx] = n; e->bandwidth[rx] = bandwidth; e->start_offset[rx] = start_offset;

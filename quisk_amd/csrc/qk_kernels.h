@@ -501,26 +501,73 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
 // Generic real-coefficient FIR with decimation on a planar stream: quisk_cDecimate / quisk_dDecimate /
 // quisk_dFilter / quisk_cFilter (filter.c:180-206, 236-262, 324-352).  Output j uses the newest input at
 // index first + D j and accumulates h[k] x[newest - k] for k = 0..T-1 in the reference's order.
-// grid (ceil(n_out/256), planes, receivers); the taps are wave-uniform (scalar loads).
+//
+// LDS-tiled.  With k = p + D q the sum of filter.c:193-199 is
+//     out[j] = sum_{p<D} sum_{q<TQP} hp[p][q] X_p[j - q],   X_p[i] = x[first + D i - p],   hp[p][q] = h[p + D q]
+// (hp zero-padded to TQP = a multiple of FT_QB taps per branch, built on the host): D unit-stride FIRs over
+// the D polyphase branches of the input.  A workgroup of NTH lanes makes NO = NTH*R consecutive outputs of
+// one (receiver, plane): it de-interleaves the input range into D LDS arrays, then every lane keeps R
+// accumulators and walks the taps FT_QB at a time with a register window of R + FT_QB - 1 samples, so an LDS
+// load feeds R*FT_QB/(R+FT_QB-1) FMAs.  R is odd: the lane stride of R doubles keeps b64 reads conflict-free.
+// The taps are wave-uniform scalar loads.  The products are summed branch by branch instead of in the
+// reference's k order (a different rounding order, inside the 1e-9 contract of DESIGN.md section 3).
 // ------------------------------------------------------------------------------------------------
-struct FirArgs {
-    StreamView in, out;
-    const double *h; int T, D, first, n_out;
-    const int *rx_list;        // receivers to process (nullptr = blockIdx.z is the receiver)
-    long long h_rx_stride;     // taps per receiver (0 = shared table)
-};
-
-__global__ __launch_bounds__(256) void k_fir_decim(FirArgs a)
+#define FT_QB 8
+template <int D, int NTH, int R>
+__device__ __forceinline__ void fir_tile(const double *__restrict__ x, const double *__restrict__ hp, int TQP,
+                                         int first, int jb, int t_max, double *lds, double (&acc)[R])
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= a.n_out) return;
+    constexpr int NO = NTH * R;
+    const int LEN = NO + TQP;
+    const int t_lo = first + D * (jb - TQP + 1) - (D - 1);
+    const int count = D * (LEN - 1);
+    for (int u = threadIdx.x; u < count; u += NTH) {
+        const int m = u / D, s = u - m * D;
+        const int t = t_lo + u;
+        lds[(D - 1 - s) * LEN + m] = t <= t_max ? x[t] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.0;
+    const int base0 = threadIdx.x * R + TQP - FT_QB;
+#pragma unroll 1
+    for (int p = 0; p < D; p++) {
+        const double *xp = lds + p * LEN + base0;
+        const double *__restrict__ h = hp + p * TQP;
+#pragma unroll 1
+        for (int qc = 0; qc < TQP; qc += FT_QB) {
+            double w[R + FT_QB - 1];
+#pragma unroll
+            for (int i = 0; i < R + FT_QB - 1; i++) w[i] = xp[i - qc];
+#pragma unroll
+            for (int qq = 0; qq < FT_QB; qq++) {
+                const double hq = h[qc + qq];
+#pragma unroll
+                for (int r = 0; r < R; r++) acc[r] = fma(w[r + FT_QB - 1 - qq], hq, acc[r]);
+            }
+        }
+    }
+}
+
+struct FirTArgs {
+    StreamView in, out;
+    const double *hp;          // [D][TQP] permuted taps
+    int TQP, first, n_out;
+    const int *rx_list;
+};
+template <int D, int NTH, int R>
+__global__ __launch_bounds__(NTH) void k_fir_tiled(FirTArgs a)
+{
+    extern __shared__ double ft_lds[];
     const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
     const int plane = blockIdx.y;
-    const double *__restrict__ p = sv_ptr(a.in, rx, plane) + a.first + (long long)a.D * j;
-    const double *__restrict__ h = a.h + a.h_rx_stride * rx;
-    double acc = 0.0;
-    for (int k = 0; k < a.T; k++) acc = fma(p[-k], h[k], acc);
-    sv_ptr(a.out, rx, plane)[j] = acc;
+    const int jb = blockIdx.x * (NTH * R);
+    double acc[R];
+    fir_tile<D, NTH, R>(sv_ptr(a.in, rx, plane), a.hp, a.TQP, a.first, jb, a.first + D * (a.n_out - 1), ft_lds, acc);
+    double *__restrict__ o = sv_ptr(a.out, rx, plane) + jb + threadIdx.x * R;
+    const int left = a.n_out - (jb + (int)threadIdx.x * R);
+#pragma unroll
+    for (int r = 0; r < R; r++) if (r < left) o[r] = acc[r];
 }
 
 // Polyphase interpolator x L (quisk_dInterpolate / quisk_cInterpolate, filter.c:108-178):
@@ -618,41 +665,49 @@ __global__ __launch_bounds__(256) void k_fracdecim(FracArgs a)
 // ------------------------------------------------------------------------------------------------
 struct RxfArgs {
     StreamView in, out;
-    const double *taps;        // [rx][2][tap_cap]  (I taps, Q taps)
+    const double *taps;        // [rx][2][tap_cap]  (I taps, Q taps), in plain FIR order h[0] = f[0], h[m] = f[N - m], zero-padded
     const int *ntaps;          // [rx]
     const int *mode;           // [rx] rx_mode_type
     int tap_cap, n, kind;
     const int *rx_list;
 };
-__global__ __launch_bounds__(256) void k_rxfilter(RxfArgs a)
+template <int NTH, int R>
+__global__ __launch_bounds__(NTH) void k_rxf_tiled(RxfArgs a)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
+    extern __shared__ double ft_lds[];
     const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
     const int N = a.ntaps[rx];
-    const double *__restrict__ pr = sv_ptr(a.in, rx, 0) + i;
-    const double *__restrict__ pi = sv_ptr(a.in, rx, 1) + i;
+    const int jb = blockIdx.x * (NTH * R), j0 = jb + threadIdx.x * R;
     const double *__restrict__ fi = a.taps + (long long)rx * 2 * a.tap_cap;
     const double *__restrict__ fq = (a.kind == 0) ? fi + a.tap_cap : fi;
-    double ar, ai;
+    double ar[R], ai[R];
     if (N == 0) {
-        ar = pr[0]; ai = pi[0];
-    } else {
-        ar = pr[0] * fi[0]; ai = pi[0] * fq[0];
-        for (int k = 1; k < N; k++) {
-            ar = fma(pr[k - N], fi[k], ar);
-            ai = fma(pi[k - N], fq[k], ai);
+        const double *pr = sv_ptr(a.in, rx, 0), *pi = sv_ptr(a.in, rx, 1);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const bool ok = j0 + r < a.n;
+            ar[r] = ok ? pr[j0 + r] : 0.0; ai[r] = ok ? pi[j0 + r] : 0.0;
         }
+    } else {
+        const int TQP = (N + FT_QB - 1) / FT_QB * FT_QB;
+        fir_tile<1, NTH, R>(sv_ptr(a.in, rx, 0), fi, TQP, 0, jb, a.n - 1, ft_lds, ar);
+        __syncthreads();
+        fir_tile<1, NTH, R>(sv_ptr(a.in, rx, 1), fq, TQP, 0, jb, a.n - 1, ft_lds, ai);
     }
+    double *o0 = sv_ptr(a.out, rx, 0) + j0;
+    const int left = a.n - j0;
     if (a.kind == 0) {
         const int m = a.mode[rx];
         const bool lower = (m == 0 /*CWL*/ || m == 2 /*LSB*/ || m == 8 /*DGT_L*/);
-        sv_ptr(a.out, rx, 0)[i] = lower ? ar + ai : ar - ai;
+#pragma unroll
+        for (int r = 0; r < R; r++) if (r < left) o0[r] = lower ? ar[r] + ai[r] : ar[r] - ai[r];
     } else if (a.kind == 1) {
-        sv_ptr(a.out, rx, 0)[i] = hypot(ar, ai);
+#pragma unroll
+        for (int r = 0; r < R; r++) if (r < left) o0[r] = hypot(ar[r], ai[r]);
     } else {
-        sv_ptr(a.out, rx, 0)[i] = ar;
-        sv_ptr(a.out, rx, 1)[i] = ai;
+        double *o1 = sv_ptr(a.out, rx, 1) + j0;
+#pragma unroll
+        for (int r = 0; r < R; r++) if (r < left) { o0[r] = ar[r]; o1[r] = ai[r]; }
     }
 }
 
@@ -780,16 +835,66 @@ __device__ __forceinline__ double wave_max_f64(double v)
     return v;
 }
 
+// The serial part of a speculation pass: G_0 = g0, G_{k+1} = G_k * keep + add (MUL) or G_k + add (!MUL), and
+// lane L >= start must end up holding G_{L - start}, the gain in force at its sample.  Every lane runs the
+// same recurrence, and the EXEC mask retires one lane per step (exec <<= 1), so a lane simply stops at its own
+// value: two dependent FP64 operations per sample and nothing else on the vector pipe -- no selects, no LDS.
+// v_mul_f64 / v_add_f64 are the separately rounded operations of the reference (quisk.c:2112, 2117); the
+// compiler cannot express the shifting EXEC mask, hence the assembly.  `steps` = (last lane) - start >= 0.
+#define AGC_S1(MULOP) "s_lshl_b64 exec, exec, 1\n\t" MULOP "v_add_f64 %[g], %[g], %[t]\n\t"
+#define AGC_S8(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M)
+#define AGC_S63(M) AGC_S8(M) AGC_S8(M) AGC_S8(M) AGC_S8(M) AGC_S8(M) AGC_S8(M) AGC_S8(M) \
+                   AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M)
+#ifdef AGC_EXP
+#define AGC_MUL ""
+#else
+#define AGC_MUL "v_mul_f64 %[g], %[g], %[k]\n\t"
+#endif
+template <bool MUL>
+__device__ __forceinline__ double agc_chain(double g0, double keep, double add, int start, int steps)
+{
+    double gv = g0;
+    unsigned long long save;
+    if (start == 0 && steps == 63) {
+        if (MUL)
+            asm volatile("s_mov_b64 %[sv], exec\n\t" AGC_S63(AGC_MUL) "s_mov_b64 exec, %[sv]\n\t"
+                         : [g] "+v"(gv), [sv] "=&s"(save) : [k] "v"(keep), [t] "v"(add) : "scc");
+        else
+            asm volatile("s_mov_b64 %[sv], exec\n\t" AGC_S63("") "s_mov_b64 exec, %[sv]\n\t"
+                         : [g] "+v"(gv), [sv] "=&s"(save) : [t] "v"(add) : "scc");
+    } else if (steps > 0) {
+        int n = steps;
+        if (MUL)
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "s_lshl_b64 exec, %[sv], %[st]\n"
+                         "1:\n\t" AGC_S1(AGC_MUL)
+                         "s_sub_u32 %[n], %[n], 1\n\t"
+                         "s_cmp_lg_u32 %[n], 0\n\t"
+                         "s_cbranch_scc1 1b\n\t"
+                         "s_mov_b64 exec, %[sv]\n\t"
+                         : [g] "+v"(gv), [n] "+s"(n), [sv] "=&s"(save) : [k] "v"(keep), [t] "v"(add), [st] "s"(start) : "scc");
+        else
+            asm volatile("s_mov_b64 %[sv], exec\n\t"
+                         "s_lshl_b64 exec, %[sv], %[st]\n"
+                         "1:\n\t" AGC_S1("")
+                         "s_sub_u32 %[n], %[n], 1\n\t"
+                         "s_cmp_lg_u32 %[n], 0\n\t"
+                         "s_cbranch_scc1 1b\n\t"
+                         "s_mov_b64 exec, %[sv]\n\t"
+                         : [g] "+v"(gv), [n] "+s"(n), [sv] "=&s"(save) : [t] "v"(add), [st] "s"(start) : "scc");
+    }
+    return gv;
+}
+
 // One WAVE per receiver.  The state machine is serial in time, but almost every sample takes one of two
 // trivial paths: "not clipping, no new clip, not at the window boundary" (gain = gain*(1-tr) + target*tr,
 // themax = max(themax, m)) or "clipping, no new maximum, ramp not finished" (gain -= delta).  The wave
-// therefore runs a tile of 64 samples SPECULATIVELY down the current path -- the serial part is only the
-// two-operation gain recurrence, whose value before each sample is dropped into that sample's lane -- and
-// then tests all 64 samples for an event (clip start, window boundary, new maximum, end of ramp) in one
-// lane-parallel pass.  Samples in front of the first event are committed, the event sample goes through
-// the full state machine (agc_step), and speculation restarts behind it.  Every floating-point operation
-// is the reference's own, in its order, without FMA contraction: the result is bit-identical to a
-// sample-by-sample walk (tests check it against the oracle).
+// therefore runs a tile of 64 samples SPECULATIVELY down the current path (agc_chain) and then tests all 64
+// samples for an event (clip start, window boundary, new maximum, end of ramp) in one lane-parallel pass.
+// Samples in front of the first event are committed, the event sample goes through the full state machine
+// (agc_step), and speculation restarts behind it.  Every floating-point operation is the reference's own,
+// in its order, without FMA contraction: the result is bit-identical to a sample-by-sample walk (tests
+// check it against the oracle).
 __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
 {
 #pragma clang fp contract(off)
@@ -804,51 +909,60 @@ __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
     c.bs = (double)a.buf_size; c.buf_size = a.buf_size;
     const int md = a.mode[rx];
     c.fm = (md == 5 || md == 13);
-    double mv = (lane < a.n) ? fabs(p[lane]) : 0.0;
+    // |x| of this tile; the raw samples of the next two tiles are in flight (a tile takes about as long as one
+    // trip to memory, and taking the magnitude at load time would wait for the load on the spot)
+    // Loads and stores are unconditional (indices clamped, the gain rows are padded to whole tiles) so that the
+    // compiler can count them in flight instead of draining the queue; lanes past the end are never `mine`.
+    const int last = a.n - 1;
+    double mv = fabs(p[min(lane, last)]);
+    double raw_a = p[min(64 + lane, last)];
+#ifdef AGC_PROF
+    long long tc = 0, tw = 0, t_begin = clock64();
+#endif
     for (int i0 = 0; i0 < a.n; i0 += 64) {
-        const int nxt = i0 + 64 + lane;
-        const double mv_next = (nxt < a.n) ? fabs(p[nxt]) : 0.0;      // in flight while this tile is walked
+        const double raw_b = p[min(i0 + 128 + lane, last)];
         const int cnt = (a.n - i0 < 64) ? a.n - i0 : 64;
         double gv = 0.0;                                               // gain in force at this lane's sample
         int start = 0;
         while (start < cnt) {
             s.pad++;                                                    // statistics: speculation passes
-            double gcur = s.gain;
             const bool mine = lane >= start && lane < cnt;
             bool ev;
+            double gnext;                                               // gain after the tile's last sample
             if (!s.is_clipping) {
                 const double tt = s.target_gain * c.tr;
-                // the serial part: 2 dependent flops per sample, computed by every lane alike (wave-uniform);
-                // lane j keeps the value in force at sample j.  The selects are off the dependent chain.
-                if (start == 0 && cnt == 64) {
-#pragma unroll
-                    for (int j = 0; j < 64; j++) { if (lane == j) gv = gcur; gcur = gcur * c.keep + tt; }
-                } else {
-                    for (int j = start; j < cnt; j++) { if (lane == j) gv = gcur; gcur = gcur * c.keep + tt; }
-                }
+#ifdef AGC_PROF
+                long long t0 = clock64();
+#endif
+                const double gs = agc_chain<true>(s.gain, c.keep, tt, start, cnt - 1 - start);
+#ifdef AGC_PROF
+                tc += clock64() - t0;
+#endif
+                if (lane >= start) gv = gs;
+                gnext = readlane_f64(gs, cnt - 1) * c.keep + tt;
                 int idx = s.index_read + (lane - start);               // buf_size >= 720 > 64: one wrap at most
                 if (idx >= a.buf_size) idx -= a.buf_size;
                 ev = mine && ((mv * gv > c.ceil_) || (idx == s.index_start));
             } else {
                 const double dl = s.delta;
-                if (start == 0 && cnt == 64) {
-#pragma unroll
-                    for (int j = 0; j < 64; j++) { if (lane == j) gv = gcur; gcur = gcur - dl; }
-                } else {
-                    for (int j = start; j < cnt; j++) { if (lane == j) gv = gcur; gcur = gcur - dl; }
-                }
+                const double gs = agc_chain<false>(s.gain, 0.0, -dl, start, cnt - 1 - start);
+                if (lane >= start) gv = gs;
+                gnext = readlane_f64(gs, cnt - 1) - dl;
                 ev = mine && ((mv > s.themax) || (gv - dl <= s.target_gain));
             }
             const unsigned long long mask = __ballot(ev);
             const int f = mask ? (int)__ffsll((long long)mask) - 1 : cnt;     // first event sample
             if (!s.is_clipping) {
-                const double red = wave_max_f64((lane >= start && lane < f) ? mv : 0.0);
-                if (s.themax < red) s.themax = red;
+                const bool inr = lane >= start && lane < f;
+                if (__ballot(inr && mv > s.themax)) {                   // rare: a new maximum among the committed samples
+                    const double red = wave_max_f64(inr ? mv : 0.0);
+                    if (s.themax < red) s.themax = red;
+                }
             }
             s.index_read += f - start;
             if (s.index_read >= a.buf_size) s.index_read -= a.buf_size;
             if (f >= cnt) {
-                s.gain = gcur;
+                s.gain = gnext;
                 start = cnt;
             } else {
                 s.gain = readlane_f64(gv, f);
@@ -856,9 +970,16 @@ __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
                 start = f + 1;
             }
         }
-        if (i0 + lane < a.n) g[i0 + lane] = gv;
-        mv = mv_next;
+        g[i0 + lane] = gv;
+#ifdef AGC_PROF
+        { long long t0 = clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tw += clock64() - t0; }
+#endif
+        mv = fabs(raw_a);
+        raw_a = raw_b;
     }
+#ifdef AGC_PROF
+    if (lane == 0 && rx == 0) printf("agc prof: n %d chain %lld wait %lld total %lld\n", a.n, tc, tw, (long long)(clock64() - t_begin));
+#endif
     if (lane == 0) a.state[rx] = s;
 }
 __global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
