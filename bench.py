@@ -122,7 +122,7 @@ def main():
         eng.process_device(ptrs[i % nb], block)
     eng.sync()
     eng.reset_stats()
-    eng.set_timing(True)
+    eng.set_timing(True, groups=(KT_FRONTEND,))      # HIP events around the front-end kernel only
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -181,7 +181,6 @@ def main():
                      "hbm": {"achieved": (16.0 * block + 16.0 * (block >> S) * nrx) / (fe_ms * 1e-3) / 1e9 if fe_ms > 0 else 0.0,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s"},
                      "share_of_step": fe_ms / (dt / a.steps * 1e3) if dt > 0 else None},
-        "device_ms_per_step": st.block_ms_sum / max(1, st.blocks_timed),
     }
     if gather_ms is not None:
         res["gather_ms"] = gather_ms

@@ -123,7 +123,9 @@ typedef struct qk_stats {
 enum { QK_KT_FRONTEND = 0, QK_KT_DECIM = 1, QK_KT_DEMOD = 2, QK_KT_AUDIO = 3, QK_KT_AGC = 4, QK_KT_FFT = 5 };
 int qk_get_stats(qk_engine *e, qk_stats *out);
 /* Per-launch HIP-event timing of the kernel groups (off by default).  Events are recorded on the engine's
- * own stream and read back at qk_get_stats, so the timed region is not synchronised. */
+ * own streams and read back at qk_get_stats, so the timed region is not synchronised.  on: 0 = off, 1 = every
+ * group and the whole block, otherwise a mask with bit (g + 1) set for each group QK_KT_g to time (bit 9 = whole
+ * block): every timed launch costs two event records, which a benchmark may not want on every kernel. */
 int qk_set_timing(qk_engine *e, int on);
 int qk_reset_stats(qk_engine *e);
 

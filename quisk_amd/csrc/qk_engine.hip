@@ -67,6 +67,8 @@ struct Chain {
     int aud = -1;              // stream index of the 48 kHz-class mono audio
     int play = -1;             // stream index of the audio at the playback rate (AGC input)
     int n_out = 0;             // audio samples of the last block
+    double *front_alt = nullptr; // front chain only: ping-pong twin of streams[0] (the front end writes block b+1 while the chain reads block b)
+    int front_last_n = 0;       // samples in the twin (the last non-empty block)
     double *play_alt = nullptr; // ping-pong twin of streams[play]: the AGC of block b runs beside the chain of block b+1
     // fractional decimator (cFracDecim, quisk.c:570-613): the position recurrence runs on the host
     double frac_dindex = 1.0;
@@ -84,8 +86,18 @@ struct qk_engine {
     qk_config cfg{};
     std::mutex mu;
     hipStream_t stream = nullptr;
-    hipStream_t agc_stream = nullptr;      // the serial AGC pass of block b overlaps the chain of block b+1
+    // Three-stage pipeline over blocks, one HIP stream per stage:
+    //   fe_stream  : input copy/unpack, display spectrum, front end (mixer + half-bands), mixer state
+    //   stream     : FIR chain, demodulators, audio chain of every class
+    //   agc_stream : the serial AGC pass (one wave per receiver)
+    // so the front end of block b+1 runs beside the chain of block b and the AGC of block b-1.
+    hipStream_t fe_stream = nullptr;
+    hipStream_t agc_stream = nullptr;
     hipEvent_t ev_chain = nullptr, ev_agc[2] = {nullptr, nullptr};
+    hipEvent_t ev_fe = nullptr;                        // front end (and head copy) of this block done
+    hipEvent_t ev_read[2] = {nullptr, nullptr};        // the chains have finished reading front-stream twin q
+    bool read_pending[2] = {false, false};
+    int fe_blocks = 0;                                 // blocks in which the front end produced output (twin parity)
     bool agc_pending = false;
     int nrx = 0, S = 0, tap_cap = DEFAULT_TAP_CAP;
     int fe_rate = 0, decim_srate = 0;
@@ -128,7 +140,7 @@ struct qk_engine {
     double smeter = -160.0 + 4.25969;
     // stats / timing
     qk_stats stats{};
-    bool timing = false;
+    unsigned timing = 0;       // bit b: time kernel group b (QK_KT_*); bit 8: the whole block
     // HIP-event timing: pairs are recorded on the engine's stream around the timed launches and read
     // back lazily (at qk_get_stats or when the pool runs out), so timing adds no host synchronisation
     std::vector<hipEvent_t> ev_pool;
@@ -267,6 +279,7 @@ static void free_chain(Chain &c)
     for (auto &st : c.stages) if (st.iir_state) hipFree(st.iir_state);
     if (c.d_members) hipFree(c.d_members);
     if (c.play_alt) hipFree(c.play_alt);
+    if (c.front_alt) hipFree(c.front_alt);
     if (c.d_frac_idx) hipFree(c.d_frac_idx);
     if (c.d_frac_pos) hipFree(c.d_frac_pos);
     if (c.d_frac_state) hipFree(c.d_frac_state);
@@ -565,6 +578,11 @@ static int init_receivers(qk_engine *e)
     }
     rc = alloc_chain_streams(e, e->front);
     if (rc != QK_OK) return rc;
+    {
+        const size_t bytes = (size_t)e->nrx * e->front.streams[0].rx_stride() * sizeof(double);
+        HIPCHECK(hipMalloc(&e->front.front_alt, bytes));
+        HIPCHECK(hipMemsetAsync(e->front.front_alt, 0, bytes, e->stream));
+    }
     rc = upload_members(e);
     if (rc != QK_OK) return rc;
     return QK_OK;
@@ -576,6 +594,10 @@ static int engine_init(qk_engine *e)
     HIPCHECK(hipSetDevice(cfg.device));
     HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHECK(hipStreamCreateWithFlags(&e->agc_stream, hipStreamNonBlocking));
+    HIPCHECK(hipStreamCreateWithFlags(&e->fe_stream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_fe, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_read[0], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_read[1], hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_chain, hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_agc[0], hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_agc[1], hipEventDisableTiming));
@@ -617,6 +639,7 @@ namespace {
 int drain_events(qk_engine *e)
 {
     if (e->ev_pending.empty()) { e->ev_next = 0; return QK_OK; }
+    HIPCHECK(hipStreamSynchronize(e->fe_stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
     HIPCHECK(hipStreamSynchronize(e->agc_stream));
     for (auto &p : e->ev_pending) {
@@ -633,7 +656,7 @@ struct Timer {      // bucket 0..7 = QK_KT_*, 8 = whole block
     qk_engine *e; int bucket; int e0 = -1; hipStream_t st;
     Timer(qk_engine *en, int b, hipStream_t stream = nullptr) : e(en), bucket(b), st(stream ? stream : en->stream)
     {
-        if (!e->timing || b < 0 || b > 8) return;
+        if (b < 0 || b > 8 || !(e->timing >> b & 1u)) return;
         if (e->ev_next + 2 > (int)e->ev_pool.size()) drain_events(e);
         e0 = e->ev_next; e->ev_next += 2;
         hipEventRecord(e->ev_pool[e0], st);
@@ -705,23 +728,23 @@ static void fft_frame(qk_engine *e, const double2 *frame)
     const int nw = (int)(floor(d2) + 0.01);
     const bool meter_on = (i0 > -N / 2 && i0 + nw + 1 < N / 2) && nw + 1 <= e->band_cap;
     a.band_start = i0; a.band_count = meter_on ? nw + 1 : 0;
-    Timer tm(e, QK_KT_FFT);
+    Timer tm(e, QK_KT_FFT, e->fe_stream);
     if (e->fftN1 > 1) {
-        hipLaunchKernelGGL(k_fft_cols, dim3(e->fftN1), dim3(FFT_THREADS), 0, e->stream, a);
-        hipLaunchKernelGGL(k_fft_rows, dim3(e->fftN1), dim3(FFT_THREADS), 0, e->stream, a);
+        hipLaunchKernelGGL(k_fft_cols, dim3(e->fftN1), dim3(FFT_THREADS), 0, e->fe_stream, a);
+        hipLaunchKernelGGL(k_fft_rows, dim3(e->fftN1), dim3(FFT_THREADS), 0, e->fe_stream, a);
     } else {
         switch (N) {
-        case 64: hipLaunchKernelGGL(k_fft_small<64>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
-        case 128: hipLaunchKernelGGL(k_fft_small<128>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
-        case 256: hipLaunchKernelGGL(k_fft_small<256>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
-        case 512: hipLaunchKernelGGL(k_fft_small<512>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
-        case 1024: hipLaunchKernelGGL(k_fft_small<1024>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
-        case 2048: hipLaunchKernelGGL(k_fft_small<2048>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
-        default: hipLaunchKernelGGL(k_fft_small<4096>, dim3(1), dim3(FFT_THREADS), 0, e->stream, a); break;
+        case 64: hipLaunchKernelGGL(k_fft_small<64>, dim3(1), dim3(FFT_THREADS), 0, e->fe_stream, a); break;
+        case 128: hipLaunchKernelGGL(k_fft_small<128>, dim3(1), dim3(FFT_THREADS), 0, e->fe_stream, a); break;
+        case 256: hipLaunchKernelGGL(k_fft_small<256>, dim3(1), dim3(FFT_THREADS), 0, e->fe_stream, a); break;
+        case 512: hipLaunchKernelGGL(k_fft_small<512>, dim3(1), dim3(FFT_THREADS), 0, e->fe_stream, a); break;
+        case 1024: hipLaunchKernelGGL(k_fft_small<1024>, dim3(1), dim3(FFT_THREADS), 0, e->fe_stream, a); break;
+        case 2048: hipLaunchKernelGGL(k_fft_small<2048>, dim3(1), dim3(FFT_THREADS), 0, e->fe_stream, a); break;
+        default: hipLaunchKernelGGL(k_fft_small<4096>, dim3(1), dim3(FFT_THREADS), 0, e->fe_stream, a); break;
         }
     }
     if (meter_on)
-        hipLaunchKernelGGL(k_meter_accum, dim3(1), dim3(64), 0, e->stream, e->d_band, nw, d2 - nw, e->d_meter);
+        hipLaunchKernelGGL(k_meter_accum, dim3(1), dim3(64), 0, e->fe_stream, e->d_band, nw, d2 - nw, e->d_meter);
     e->fft_count++;
     e->stats.fft_frames++;
 }
@@ -740,7 +763,7 @@ static int feed_spectrum(qk_engine *e, const double2 *x, int n)
             continue;
         }
         const int take = std::min(N - e->fft_fill, n - pos);
-        HIPCHECK(hipMemcpyAsync(e->d_fft_stage + e->fft_fill, x + pos, sizeof(double2) * take, hipMemcpyDeviceToDevice, e->stream));
+        HIPCHECK(hipMemcpyAsync(e->d_fft_stage + e->fft_fill, x + pos, sizeof(double2) * take, hipMemcpyDeviceToDevice, e->fe_stream));
         e->fft_fill += take; pos += take;
         if (e->fft_fill == N) { fft_frame(e, e->d_fft_stage); e->fft_fill = 0; }
     }
@@ -760,17 +783,17 @@ static int release_graph(qk_engine *e, double zoom, double deltaf, double *out, 
         k0[i] = (int)(N * (deltaf / e->cfg.sample_rate + zoom * ((double)i / W - 0.5) + 0.5) + 0.1);   // quisk.c:4720-4721
         if (i >= 1 && k0[i] < i && k0[i] + n - 1 >= 0) alias = true;   // would read a pixel already written in place
     }
-    HIPCHECK(hipMemcpyAsync(e->d_k0, k0.data(), sizeof(int) * W, hipMemcpyHostToDevice, e->stream));
+    HIPCHECK(hipMemcpyAsync(e->d_k0, k0.data(), sizeof(int) * W, hipMemcpyHostToDevice, e->fe_stream));
     ReleaseArgs ra{e->d_fft_avg, e->d_graph, e->d_k0, N, e->fftN1, W, n,
                    20.0 * (log10((double)count) + log10((double)N) + 31.0 * log10(2.0))};          // quisk.c:4741-4742
-    if (alias) hipLaunchKernelGGL(k_graph_release_inplace, dim3(1), dim3(256), 0, e->stream, ra, e->d_pix);
-    else hipLaunchKernelGGL(k_graph_release, dim3((W + 3) / 4), dim3(256), 0, e->stream, ra);
+    if (alias) hipLaunchKernelGGL(k_graph_release_inplace, dim3(1), dim3(256), 0, e->fe_stream, ra, e->d_pix);
+    else hipLaunchKernelGGL(k_graph_release, dim3((W + 3) / 4), dim3(256), 0, e->fe_stream, ra);
     double meter = 0;
-    HIPCHECK(hipMemcpyAsync(out, e->d_graph, sizeof(double) * W, hipMemcpyDeviceToHost, e->stream));
-    HIPCHECK(hipMemcpyAsync(&meter, e->d_meter, sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIPCHECK(hipMemsetAsync(e->d_fft_avg, 0, sizeof(double) * N, e->stream));
-    HIPCHECK(hipMemsetAsync(e->d_meter, 0, sizeof(double), e->stream));
-    HIPCHECK(hipStreamSynchronize(e->stream));
+    HIPCHECK(hipMemcpyAsync(out, e->d_graph, sizeof(double) * W, hipMemcpyDeviceToHost, e->fe_stream));
+    HIPCHECK(hipMemcpyAsync(&meter, e->d_meter, sizeof(double), hipMemcpyDeviceToHost, e->fe_stream));
+    HIPCHECK(hipMemsetAsync(e->d_fft_avg, 0, sizeof(double) * N, e->fe_stream));
+    HIPCHECK(hipMemsetAsync(e->d_meter, 0, sizeof(double), e->fe_stream));
+    HIPCHECK(hipStreamSynchronize(e->fe_stream));
     const double scale = 1.0 / 2147483647.0 / N;                    // quisk.c:4728-4737
     double sm = meter * scale * scale / count;
     sm = sm > 0 ? 10.0 * log10(sm) : -160.0;
@@ -911,9 +934,9 @@ static void launch_frontend(qk_engine *e, const FrontArgs &fa, int nspans)
 {
     if (e->fe_variant == 0) {
         const size_t lds = FeLayout<FE_CHUNK>::total(S) * sizeof(double);
-        hipLaunchKernelGGL((k_frontend<S, FE_CHUNK>), dim3(nspans, e->nrx), dim3(FE_THREADS), lds, e->stream, fa);
+        hipLaunchKernelGGL((k_frontend<S, FE_CHUNK>), dim3(nspans, e->nrx), dim3(FE_THREADS), lds, e->fe_stream, fa);
     } else {
-        hipLaunchKernelGGL((k_frontend_wave<S>), dim3(nspans, e->nrx), dim3(64), 0, e->stream, fa);
+        hipLaunchKernelGGL((k_frontend_wave<S>), dim3(nspans, e->nrx), dim3(64), 0, e->fe_stream, fa);
     }
 }
 
@@ -937,16 +960,24 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     fa.x = x; fa.n = n; fa.N0 = e->N0;
     fa.hist = e->d_mixhist[e->pp]; fa.H = e->H;
     fa.mt = MixTables{e->d_tabA, e->d_tabB, e->d_tabC, e->d_v0[e->pp], e->d_mix_on, e->nA};
-    fa.out = F.streams[0].view();
     fa.J0 = e->N0 >> S;
     fa.g_lo0 = fa.J0 << S;
     fa.g_end = ((e->N0 + n) >> S) << S;
     const long long consumed = fa.g_end - fa.g_lo0;
     F.streams[0].n = (int)(consumed >> S);
+    // The front end's output stream is double-buffered: this block goes into the twin, which the chains of the
+    // block before last were the last to read (ev_read of that twin).
+    const bool fe_writes = F.streams[0].n > 0;
+    const int q = e->fe_blocks & 1;
+    if (fe_writes) {
+        std::swap(F.streams[0].d, F.front_alt);
+        if (e->read_pending[q]) HIPCHECK(hipStreamWaitEvent(e->fe_stream, e->ev_read[q], 0));
+    }
+    fa.out = F.streams[0].view();
     {
-        Timer tm(e, QK_KT_FRONTEND);
+        Timer tm(e, QK_KT_FRONTEND, e->fe_stream);
         if (S == 0) {
-            hipLaunchKernelGGL(k_mix_only, dim3((n + 255) / 256, e->nrx), dim3(256), 0, e->stream, fa);
+            hipLaunchKernelGGL(k_mix_only, dim3((n + 255) / 256, e->nrx), dim3(256), 0, e->fe_stream, fa);
         } else if (consumed > 0) {
             // spans: enough workgroups to fill 256 CUs several times over, but long enough that the warm-up
             // (44 * 2^S samples per span) stays a small fraction
@@ -968,13 +999,24 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         }
     }
     if (S > 0)
-        hipLaunchKernelGGL(k_mixhist_update, dim3((e->H + 255) / 256, e->nrx), dim3(256), 0, e->stream, fa,
+        hipLaunchKernelGGL(k_mixhist_update, dim3((e->H + 255) / 256, e->nrx), dim3(256), 0, e->fe_stream, fa,
                            e->d_mixhist[e->pp ^ 1], e->d_v0[e->pp ^ 1]);
     else
-        hipLaunchKernelGGL(k_mixhist_update, dim3(1, e->nrx), dim3(256), 0, e->stream, fa,
+        hipLaunchKernelGGL(k_mixhist_update, dim3(1, e->nrx), dim3(256), 0, e->fe_stream, fa,
                            e->d_mixhist[e->pp ^ 1], e->d_v0[e->pp ^ 1]);
     e->pp ^= 1;
     e->N0 += n;
+    if (fe_writes) {
+        // head copy: the last `hist` samples of the previous block (in the twin) go in front of this one
+        Stream &f0 = F.streams[0];
+        TailArgs th{}; th.count = 1; th.rx_list = nullptr;
+        th.t[0] = TailDesc{F.front_alt, f0.rx_stride(), f0.hist + f0.cap, f0.planes, f0.hist, F.front_last_n, f0.d};
+        if (f0.hist > 0 && F.front_last_n > 0)
+            hipLaunchKernelGGL(k_save_tails, dim3(1, 2, e->nrx), dim3(256), 0, e->fe_stream, th);
+        F.front_last_n = f0.n;
+    }
+    HIPCHECK(hipEventRecord(e->ev_fe, e->fe_stream));
+    HIPCHECK(hipStreamWaitEvent(e->stream, e->ev_fe, 0));
     // ---- remaining integer decimation, all receivers ----
     int rc = run_chain(e, F, F.streams[0], nullptr, e->nrx);
     if (rc != QK_OK) return rc;
@@ -999,6 +1041,11 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     const int par = (int)(e->stats.blocks & 1);
     HIPCHECK(hipEventRecord(e->ev_chain, e->stream));
     HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_chain, 0));
+    if (fe_writes) {
+        HIPCHECK(hipEventRecord(e->ev_read[q], e->stream));
+        e->read_pending[q] = true;
+        e->fe_blocks++;
+    }
     for (int cl = 0; cl < CL_COUNT; cl++) {
         Chain &c = e->cls_chain[cl];
         const int nl = (int)c.members.size(), m = c.n_out;
@@ -1024,7 +1071,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     // ---- carry stream tails ----
     {
         TailArgs ta{}; ta.count = 0; ta.rx_list = nullptr;
-        add_tails(ta, F, -1);
+        add_tails(ta, F, 0);        // stream 0 is carried by the head copy
         if (ta.count) hipLaunchKernelGGL(k_save_tails, dim3(ta.count, 2, e->nrx), dim3(256), 0, e->stream, ta);
         // the play streams' tails go into the twin buffers, which the previous block's AGC pass may still be reading
         if (e->agc_pending) HIPCHECK(hipStreamWaitEvent(e->stream, e->ev_agc[par ^ 1], 0));
@@ -1089,6 +1136,7 @@ void qk_destroy(qk_engine *e)
 {
     if (!e) return;
     hipSetDevice(e->cfg.device);
+    if (e->fe_stream) hipStreamSynchronize(e->fe_stream);
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->agc_stream) hipStreamSynchronize(e->agc_stream);
     free_chain(e->front);
@@ -1103,6 +1151,9 @@ void qk_destroy(qk_engine *e)
     if (e->agc_stream) { hipStreamSynchronize(e->agc_stream); hipStreamDestroy(e->agc_stream); }
     if (e->ev_chain) hipEventDestroy(e->ev_chain);
     for (auto &ev : e->ev_agc) if (ev) hipEventDestroy(ev);
+    if (e->ev_fe) hipEventDestroy(e->ev_fe);
+    for (auto &ev : e->ev_read) if (ev) hipEventDestroy(ev);
+    if (e->fe_stream) hipStreamDestroy(e->fe_stream);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1111,7 +1162,8 @@ void qk_destroy(qk_engine *e)
     if (!(e)) return fail(QK_EINVAL, "null engine");                     \
     std::lock_guard<std::mutex> _lk((e)->mu);                            \
     HIPCHECK(hipSetDevice((e)->cfg.device))
-#define SYNC_ALL(e) do { HIPCHECK(hipStreamSynchronize((e)->stream)); HIPCHECK(hipStreamSynchronize((e)->agc_stream)); } while (0)
+#define SYNC_ALL(e) do { HIPCHECK(hipStreamSynchronize((e)->fe_stream)); HIPCHECK(hipStreamSynchronize((e)->stream)); \
+                         HIPCHECK(hipStreamSynchronize((e)->agc_stream)); } while (0)
 #define RX_CHECK(e, rx) if ((rx) < 0 || (rx) >= (e)->nrx) return fail(QK_ERANGE, "receiver index out of range")
 
 int qk_set_tune(qk_engine *e, int rx, int tune_hz)
@@ -1187,7 +1239,7 @@ int qk_process_samples(qk_engine *e, const double *iq_host, int n)
     if (!iq_host && n > 0) return fail(QK_EINVAL, "null sample pointer");
     if (n > 0) {
         SYNC_ALL(e);      // the previous block may still read d_in
-        HIPCHECK(hipMemcpyAsync(e->d_in, iq_host, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, e->stream));
+        HIPCHECK(hipMemcpyAsync(e->d_in, iq_host, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, e->fe_stream));
     }
     return process_device(e, e->d_in, n);
 }
@@ -1206,8 +1258,8 @@ int qk_process_samples_int(qk_engine *e, const void *raw, size_t n_bytes, int by
         e->raw_cap = (size_t)e->cfg.max_block * 8;
         HIPCHECK(hipMalloc(&e->d_raw, e->raw_cap));
     }
-    HIPCHECK(hipMemcpyAsync(e->d_raw, raw, n_bytes, hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(k_unpack_int, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->d_raw, e->d_in, (int)n,
+    HIPCHECK(hipMemcpyAsync(e->d_raw, raw, n_bytes, hipMemcpyHostToDevice, e->fe_stream));
+    hipLaunchKernelGGL(k_unpack_int, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->fe_stream, e->d_raw, e->d_in, (int)n,
                        bytes, big_endian);
     return process_device(e, e->d_in, (int)n);
 }
@@ -1292,7 +1344,7 @@ int qk_set_timing(qk_engine *e, int on)
 {
     ENGINE_ENTER(e);
     int rc = drain_events(e);
-    e->timing = on != 0;
+    e->timing = on == 1 ? 0x1ffu : (unsigned)on >> 1;     // 1 = everything; otherwise bit (b + 1) selects group b
     return rc;
 }
 
@@ -1379,7 +1431,7 @@ long long qk_debug_agc_passes(qk_engine *e, int rx)
     if (!e || rx < 0 || rx >= e->nrx) return -1;
     std::lock_guard<std::mutex> lk(e->mu);
     hipSetDevice(e->cfg.device);
-    hipStreamSynchronize(e->stream); hipStreamSynchronize(e->agc_stream);
+    hipStreamSynchronize(e->fe_stream); hipStreamSynchronize(e->stream); hipStreamSynchronize(e->agc_stream);
     AgcState st;
     if (hipMemcpy(&st, e->d_agc + rx, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return st.pad;

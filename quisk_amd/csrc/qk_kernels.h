@@ -900,6 +900,7 @@ __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
 #pragma clang fp contract(off)
     const int rx = a.rx_list ? a.rx_list[blockIdx.x] : blockIdx.x;
     if (!a.started[rx]) return;
+    __builtin_amdgcn_s_setprio(3);      // a latency-bound wave among the front end's throughput-bound ones: issue first
     const int lane = threadIdx.x;
     const double *__restrict__ p = sv_ptr(a.in, rx, 0);
     double *__restrict__ g = a.gains + (long long)rx * a.gain_stride;
@@ -909,18 +910,20 @@ __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
     c.bs = (double)a.buf_size; c.buf_size = a.buf_size;
     const int md = a.mode[rx];
     c.fm = (md == 5 || md == 13);
-    // |x| of this tile; the raw samples of the next two tiles are in flight (a tile takes about as long as one
-    // trip to memory, and taking the magnitude at load time would wait for the load on the spot)
-    // Loads and stores are unconditional (indices clamped, the gain rows are padded to whole tiles) so that the
-    // compiler can count them in flight instead of draining the queue; lanes past the end are never `mine`.
+    // The raw samples of the next two tiles are always in flight: a tile takes about as long as one trip to
+    // memory.  Loads and stores are unconditional (indices clamped, the gain rows are padded to whole tiles) so
+    // that the compiler can count them in flight instead of draining the queue; lanes past the end are never
+    // `mine`.  The tile loop is unrolled by hand by the depth of the rotation (three registers), so that no
+    // register copy has to wait for a load that was only just issued.
     const int last = a.n - 1;
-    double mv = fabs(p[min(lane, last)]);
-    double raw_a = p[min(64 + lane, last)];
 #ifdef AGC_PROF
-    long long tc = 0, tw = 0, t_begin = clock64();
+    long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = clock64(), t_begin = t_last;
+#define AGC_PROBE(k) do { const long long t_ = clock64(); tp[k] += t_ - t_last; t_last = clock64(); tp[7] += t_last - t_; } while (0)
+#else
+#define AGC_PROBE(k) do { } while (0)
 #endif
-    for (int i0 = 0; i0 < a.n; i0 += 64) {
-        const double raw_b = p[min(i0 + 128 + lane, last)];
+    auto tile = [&](const int i0, const double mv) {
+        AGC_PROBE(0);                                                   // tile loop: load issue, wait, magnitude
         const int cnt = (a.n - i0 < 64) ? a.n - i0 : 64;
         double gv = 0.0;                                               // gain in force at this lane's sample
         int start = 0;
@@ -928,57 +931,75 @@ __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
             s.pad++;                                                    // statistics: speculation passes
             const bool mine = lane >= start && lane < cnt;
             bool ev;
-            double gnext;                                               // gain after the tile's last sample
+            int fmax = cnt;                                             // first sample that is an event for a wave-uniform reason
+            double gs, step_add;
             if (!s.is_clipping) {
                 const double tt = s.target_gain * c.tr;
-#ifdef AGC_PROF
-                long long t0 = clock64();
-#endif
-                const double gs = agc_chain<true>(s.gain, c.keep, tt, start, cnt - 1 - start);
-#ifdef AGC_PROF
-                tc += clock64() - t0;
-#endif
+                AGC_PROBE(1);
+                gs = agc_chain<true>(s.gain, c.keep, tt, start, cnt - 1 - start);
+                AGC_PROBE(2);                                           // the chain
                 if (lane >= start) gv = gs;
-                gnext = readlane_f64(gs, cnt - 1) * c.keep + tt;
-                int idx = s.index_read + (lane - start);               // buf_size >= 720 > 64: one wrap at most
-                if (idx >= a.buf_size) idx -= a.buf_size;
-                ev = mine && ((mv * gv > c.ceil_) || (idx == s.index_start));
+                step_add = tt;
+                // the window boundary (index_read == index_start) falls on a lane known in advance
+                int ahead = s.index_start - s.index_read;
+                if (ahead < 0) ahead += a.buf_size;
+                if (start + ahead < cnt) fmax = start + ahead;
+                ev = mine && (mv * gv > c.ceil_);
             } else {
                 const double dl = s.delta;
-                const double gs = agc_chain<false>(s.gain, 0.0, -dl, start, cnt - 1 - start);
+                gs = agc_chain<false>(s.gain, 0.0, -dl, start, cnt - 1 - start);
                 if (lane >= start) gv = gs;
-                gnext = readlane_f64(gs, cnt - 1) - dl;
+                step_add = -dl;
                 ev = mine && ((mv > s.themax) || (gv - dl <= s.target_gain));
             }
             const unsigned long long mask = __ballot(ev);
-            const int f = mask ? (int)__ffsll((long long)mask) - 1 : cnt;     // first event sample
+            int f = mask ? (int)__ffsll((long long)mask) - 1 : cnt;           // first event sample
+            if (fmax < f) f = fmax;
+            AGC_PROBE(3);                                               // event test
             if (!s.is_clipping) {
+                // themax = max(themax, |x| of the committed samples): walk the successive record holders instead of
+                // reducing over the wave -- there are about ln(64) of them at worst on noise, usually none
                 const bool inr = lane >= start && lane < f;
-                if (__ballot(inr && mv > s.themax)) {                   // rare: a new maximum among the committed samples
-                    const double red = wave_max_f64(inr ? mv : 0.0);
-                    if (s.themax < red) s.themax = red;
+                unsigned long long over = __ballot(inr && mv > s.themax);
+                while (over) {
+                    s.themax = readlane_f64(mv, (int)__ffsll((long long)over) - 1);
+                    over = __ballot(inr && mv > s.themax);
                 }
             }
+            AGC_PROBE(4);                                               // window maximum
             s.index_read += f - start;
             if (s.index_read >= a.buf_size) s.index_read -= a.buf_size;
             if (f >= cnt) {
-                s.gain = gnext;
+                const double glast = readlane_f64(gs, cnt - 1);        // gain in force at the last sample: one more step
+                s.gain = s.is_clipping ? glast + step_add : glast * c.keep + step_add;
                 start = cnt;
             } else {
                 s.gain = readlane_f64(gv, f);
                 agc_step(s, readlane_f64(mv, f), c);
                 start = f + 1;
             }
+            AGC_PROBE(5);                                               // commit / event step
         }
         g[i0 + lane] = gv;
-#ifdef AGC_PROF
-        { long long t0 = clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tw += clock64() - t0; }
-#endif
-        mv = fabs(raw_a);
-        raw_a = raw_b;
+        AGC_PROBE(6);
+    };
+    // (the prologue loads are consumed here, so the loop is entered with nothing in flight and its waits count
+    // only what the loop itself issued)
+    double ra = fabs(p[min(lane, last)]), rb = fabs(p[min(64 + lane, last)]), rc;
+    for (int i0 = 0; i0 < a.n; i0 += 192) {
+        rc = p[min(i0 + 128 + lane, last)];
+        tile(i0, fabs(ra));
+        if (i0 + 64 >= a.n) break;
+        ra = p[min(i0 + 192 + lane, last)];
+        tile(i0 + 64, fabs(rb));
+        if (i0 + 128 >= a.n) break;
+        rb = p[min(i0 + 256 + lane, last)];
+        tile(i0 + 128, fabs(rc));
     }
 #ifdef AGC_PROF
-    if (lane == 0 && rx == 0) printf("agc prof: n %d chain %lld wait %lld total %lld\n", a.n, tc, tw, (long long)(clock64() - t_begin));
+    if (lane == 0 && rx == 0)
+        printf("agc prof: n %d total %lld | loop %lld pre %lld chain %lld event %lld max %lld commit %lld store %lld probe %lld\n", a.n,
+               (long long)(clock64() - t_begin), tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7]);
 #endif
     if (lane == 0) a.state[rx] = s;
 }

@@ -146,8 +146,14 @@ class Engine:
     def set_agc_release_time(self, seconds):
         _check(self.L.qk_set_agc_release_time(self.h, float(seconds)))
 
-    def set_timing(self, on):
-        _check(self.L.qk_set_timing(self.h, int(bool(on))))
+    def set_timing(self, on, groups=None):
+        """on: time every kernel group; groups: iterable of KT_* to time only those (cheaper)."""
+        v = int(bool(on))
+        if on and groups is not None:
+            v = 0
+            for g in groups:
+                v |= 2 << int(g)
+        _check(self.L.qk_set_timing(self.h, v))
 
     # ---- data path ----
     def process(self, iq):
