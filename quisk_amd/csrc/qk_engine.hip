@@ -726,12 +726,13 @@ static void fft_frame(qk_engine *e, const double2 *frame)
     const double d2 = (double)bw * N / fs;
     const int i0 = (int)((double)(tune + off) * N / fs + 0.5);
     const int nw = (int)(floor(d2) + 0.01);
-    const bool meter_on = (i0 > -N / 2 && i0 + nw + 1 < N / 2) && nw + 1 <= e->band_cap;
+    // (a zero bandwidth adds nothing to the sum: no launch)
+    const bool meter_on = bw > 0 && (i0 > -N / 2 && i0 + nw + 1 < N / 2) && nw + 1 <= e->band_cap;
     a.band_start = i0; a.band_count = meter_on ? nw + 1 : 0;
     Timer tm(e, QK_KT_FFT, e->fe_stream);
     if (e->fftN1 > 1) {
-        hipLaunchKernelGGL(k_fft_cols, dim3(e->fftN1), dim3(FFT_THREADS), 0, e->fe_stream, a);
-        hipLaunchKernelGGL(k_fft_rows, dim3(e->fftN1), dim3(FFT_THREADS), 0, e->fe_stream, a);
+        hipLaunchKernelGGL(k_fft_cols, dim3(e->fftN1), dim3(FFT_BIG_THREADS), 0, e->fe_stream, a);
+        hipLaunchKernelGGL(k_fft_rows, dim3(e->fftN1), dim3(FFT_BIG_THREADS), 0, e->fe_stream, a);
     } else {
         switch (N) {
         case 64: hipLaunchKernelGGL(k_fft_small<64>, dim3(1), dim3(FFT_THREADS), 0, e->fe_stream, a); break;

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #define FFT_THREADS 256
+#define FFT_BIG_THREADS 1024      // four-step passes: one butterfly per lane and pass, 16 waves hide the LDS and HBM latency
 
 __device__ __forceinline__ double2 cmul_d(double2 a, double2 b)
 {
@@ -24,10 +25,10 @@ __device__ __forceinline__ double2 cmul_d(double2 a, double2 b)
 // Stockham autosort passes over an LDS array of TOTAL = n * s complex values holding s interleaved sequences of
 // length n (element (p, q) at q + s p).  tw4096[j] = exp(-2 pi i j / 4096).  In place: every pass reads all its
 // operands into registers, synchronises, then writes.  Result: natural order, same interleaving.
-template <int TOTAL>
+template <int TOTAL, int NT = FFT_THREADS>
 __device__ __forceinline__ void lds_fft(double2 *buf, int n, int s, const double2 *__restrict__ tw4096)
 {
-    constexpr int PER4 = (TOTAL / 4 + FFT_THREADS - 1) / FFT_THREADS;
+    constexpr int PER4 = (TOTAL / 4 + NT - 1) / NT;
     const int tid = threadIdx.x;
     while (n >= 4) {
         const int n1 = n >> 2;
@@ -36,7 +37,7 @@ __device__ __forceinline__ void lds_fft(double2 *buf, int n, int s, const double
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER4; u++) {
-            const int t = tid + u * FFT_THREADS;
+            const int t = tid + u * NT;
             if (t < TOTAL / 4) {
                 const int p = t / s, q = t - p * s;
                 a[u] = buf[q + s * p];
@@ -48,7 +49,7 @@ __device__ __forceinline__ void lds_fft(double2 *buf, int n, int s, const double
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER4; u++) {
-            const int t = tid + u * FFT_THREADS;
+            const int t = tid + u * NT;
             if (t < TOTAL / 4) {
                 const int p = t / s, q = t - p * s;
                 const double2 apc = make_double2(a[u].x + c[u].x, a[u].y + c[u].y);
@@ -74,18 +75,18 @@ __device__ __forceinline__ void lds_fft(double2 *buf, int n, int s, const double
         n >>= 2; s <<= 2;
     }
     if (n == 2) {       // one radix-2 pass finishes sizes 2 * 4^m: p = 0 only, no twiddle
-        constexpr int PER2 = (TOTAL / 2 + FFT_THREADS - 1) / FFT_THREADS;
+        constexpr int PER2 = (TOTAL / 2 + NT - 1) / NT;
         double2 a[PER2], b[PER2];
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER2; u++) {
-            const int q = tid + u * FFT_THREADS;
+            const int q = tid + u * NT;
             if (q < TOTAL / 2) { a[u] = buf[q]; b[u] = buf[q + s]; }
         }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < PER2; u++) {
-            const int q = tid + u * FFT_THREADS;
+            const int q = tid + u * NT;
             if (q < TOTAL / 2) {
                 buf[q] = make_double2(a[u].x + b[u].x, a[u].y + b[u].y);
                 buf[q + s] = make_double2(a[u].x - b[u].x, a[u].y - b[u].y);
@@ -131,20 +132,20 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_small(FftArgs a)
 }
 
 // pass A: blockIdx.x = column tile; TW = 4096 / N1 columns per tile
-__global__ __launch_bounds__(FFT_THREADS) void k_fft_cols(FftArgs a)
+__global__ __launch_bounds__(FFT_BIG_THREADS) void k_fft_cols(FftArgs a)
 {
     __shared__ __attribute__((aligned(16))) double2 buf[4096];
     const int N1 = a.N1, TW = 4096 / N1;
     const int c0 = blockIdx.x * TW;
-    for (int e = threadIdx.x; e < 4096; e += FFT_THREADS) {
+    for (int e = threadIdx.x; e < 4096; e += FFT_BIG_THREADS) {
         const int n1 = e / TW, col = e - n1 * TW;
         const long long idx = (long long)n1 * 4096 + c0 + col;          // x[N2 n1 + n2]
         const double2 v = a.x[idx];
         const double w = a.window[idx];
         buf[e] = make_double2(v.x * w, v.y * w);
     }
-    lds_fft<4096>(buf, N1, TW, a.tw4096);
-    for (int e = threadIdx.x; e < 4096; e += FFT_THREADS) {
+    lds_fft<4096, FFT_BIG_THREADS>(buf, N1, TW, a.tw4096);
+    for (int e = threadIdx.x; e < 4096; e += FFT_BIG_THREADS) {
         const int k1 = e / TW, col = e - k1 * TW;
         const int n2 = c0 + col;
         const long long t = (long long)n2 * k1;                          // < N
@@ -154,14 +155,14 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_cols(FftArgs a)
 }
 
 // pass B: blockIdx.x = k1
-__global__ __launch_bounds__(FFT_THREADS) void k_fft_rows(FftArgs a)
+__global__ __launch_bounds__(FFT_BIG_THREADS) void k_fft_rows(FftArgs a)
 {
     __shared__ __attribute__((aligned(16))) double2 buf[4096];
     const int k1 = blockIdx.x;
     const double2 *row = a.Y + (long long)k1 * 4096;
-    for (int e = threadIdx.x; e < 4096; e += FFT_THREADS) buf[e] = row[e];
-    lds_fft<4096>(buf, 4096, 1, a.tw4096);
-    for (int e = threadIdx.x; e < 4096; e += FFT_THREADS) fft_epilogue(a, k1, e, buf[e]);
+    for (int e = threadIdx.x; e < 4096; e += FFT_BIG_THREADS) buf[e] = row[e];
+    lds_fft<4096, FFT_BIG_THREADS>(buf, 4096, 1, a.tw4096);
+    for (int e = threadIdx.x; e < 4096; e += FFT_BIG_THREADS) fft_epilogue(a, k1, e, buf[e]);
 }
 
 // S-meter accumulation of one frame, in the reference's order (quisk.c:4668-4679): whole bins, then the
