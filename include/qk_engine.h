@@ -37,7 +37,8 @@ typedef struct qk_config {
     int playback_rate;     /* audio rate: 48000 x {1,2,4,8} (quisk.c:2535-2553) */
     int n_receivers;       /* number of independent receivers (reference: 3 banks); 0 = spectrum only */
     int max_block;         /* largest n accepted by qk_process_* (reference: SAMP_BUFFER_SIZE 66000, quisk.h:15) */
-    int fft_size;          /* display FFT size, power of two, or 0 for no spectrum (record_app, quisk.c:5054) */
+    int fft_size;          /* display FFT size (any, e.g. data_width * fft_mult, quisk.py:3858-3890; powers of two run the
+                              direct transform) or 0 for no spectrum (record_app, quisk.c:5054) */
     int data_width;        /* graph points returned by qk_get_graph (record_app, quisk.c:5054) */
     int reserved[8];       /* [0] = largest receive-filter length accepted by qk_set_filters (0 = 1024); rest zero */
 } qk_config;
@@ -100,6 +101,23 @@ double qk_get_smeter(qk_engine *e);
 int qk_graph_pending(qk_engine *e);
 /* Device pointer to the last released graph row (data_width doubles), for the RCCL gather. */
 int qk_graph_device(qk_engine *e, const double **dev_ptr);
+
+/* get_multirx_graph (quisk.c:4468-4530), the transform of one sub-receiver's frame: iq_host holds
+ * 8 * data_width complex samples (multirx_fft_width, quisk.c:5098); periodic Hann window (4481-4482), forward FFT,
+ * 8 -> 1 magnitude binning in order of frequency and dB scaling (4491-4519) into out[data_width].  Which
+ * sub-receiver's turn it is and the refresh timer (quisk.c:3538-3548, 4485) stay with the caller. */
+int qk_multirx_graph(qk_engine *e, const double *iq_host, int data_width, double *out);
+/* Bandscope (Hermes ADC samples).  qk_bandscope_init = init_bandscope (quisk.c:2758-2775); size = 512 * blocks.
+ * qk_add_bscope_samples: one block of `size` real samples already scaled to +-1 (read_rx_udp10, quisk.c:3411-3428);
+ * _int: add_bscope_samples (quisk.c:2841-2900), signed integers of `bytes` bytes, scaled by 1 / CLIP32.  Each block
+ * is windowed, transformed and its magnitudes added to the average at once (quisk.c:4545-4558).
+ * qk_get_bandscope = the release half of get_bandscope (quisk.c:4559-4595) without its wall-clock gate: returns the
+ * number of blocks averaged (0 = none, out untouched), writes graph_width dB values and the largest |sample| seen
+ * (hermes_adc_level), and clears the average. */
+int qk_bandscope_init(qk_engine *e, int size);
+int qk_add_bscope_samples(qk_engine *e, const double *samples_host, int n);
+int qk_add_bscope_samples_int(qk_engine *e, const void *raw_host, size_t n_bytes, int bytes, int big_endian);
+int qk_get_bandscope(qk_engine *e, int clock, double zoom, double deltaf, double *out, int graph_width, double *adc_level);
 
 /* get_filter_rate (quisk.c:2661-2735) and PlanDecimation (quisk.c:1509-1547): pure functions. */
 int qk_get_filter_rate(int sample_rate, int mode, int bandwidth);

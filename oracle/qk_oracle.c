@@ -768,10 +768,54 @@ void qko_rx_process_many(qko_rx **rx, int nrx, const qko_cd *x, int n, qko_cd *o
 
 /* ================================ quisk.c: display spectrum ========================= */
 
+/* any length: recursive decimation in time over the prime factors of n (direct p-point sums at each level),
+ * twiddles from one table of cexp values.  Stands where the reference calls FFTW3 on sizes such as
+ * data_width * fft_mult (quisk.py:3858-3890) and 8 * multirx_data_width (quisk.c:5098). */
+static void fft_any_rec(const qko_cd *in, qko_cd *out, int n, int stride, const qko_cd *w, int N)
+{
+    int p, m, r, k, q;
+    qko_cd t[64];
+    if (n == 1) { out[0] = in[0]; return; }
+    for (p = 2; p * p <= n && n % p; p++) ;
+    if (n % p) p = n;
+    m = n / p;
+    if (p > 64) {       /* a large prime factor: plain DFT of this level */
+        qko_cd *tmp = (qko_cd *)malloc((size_t)n * sizeof(qko_cd));
+        for (k = 0; k < n; k++) {
+            qko_cd acc = 0;
+            for (r = 0; r < n; r++) acc += in[(size_t)r * stride] * w[(size_t)(((long long)r * k) % n) * (N / n)];
+            tmp[k] = acc;
+        }
+        memcpy(out, tmp, (size_t)n * sizeof(qko_cd));
+        free(tmp);
+        return;
+    }
+    for (r = 0; r < p; r++) fft_any_rec(in + (size_t)r * stride, out + (size_t)r * m, m, stride * p, w, N);
+    for (k = 0; k < m; k++) {
+        for (r = 0; r < p; r++) t[r] = out[(size_t)r * m + k] * w[(size_t)(((long long)r * k) % n) * (N / n)];
+        for (q = 0; q < p; q++) {
+            qko_cd acc = t[0];
+            for (r = 1; r < p; r++) acc += t[r] * w[(size_t)((((long long)r * q) % p) * m) * (N / n)];
+            out[(size_t)k + (size_t)m * q] = acc;
+        }
+    }
+}
+static void fft_any(qko_cd *x, int n)
+{
+    int i;
+    qko_cd *w = (qko_cd *)malloc((size_t)n * sizeof(qko_cd)), *in = (qko_cd *)malloc((size_t)n * sizeof(qko_cd));
+    for (i = 0; i < n; i++) w[i] = cexp(-2.0 * M_PI * I * (double)i / (double)n);
+    memcpy(in, x, (size_t)n * sizeof(qko_cd));
+    fft_any_rec(in, x, n, 1, w, n);
+    free(w); free(in);
+}
+
 void qko_fft(qko_cd *x, int n)
 {   /* plain radix-2 decimation in time; twiddles from cexp per index, so the error stays ~1e-16 log2 n */
     int i, j, len, k, bits = 0;
     qko_cd *w;
+    if (n < 1) return;
+    if (n & (n - 1)) { fft_any(x, n); return; }
     while ((1 << bits) < n) bits++;
     for (i = 0; i < n; i++) {
         unsigned r = 0, v = (unsigned)i;
@@ -867,5 +911,82 @@ int qko_graph_release(qko_graph *g, double zoom, double deltaf, double *out, dou
     }
     for (i = 0; i < N; i++) g->avg[i] = 0;
     g->count = 0;
+    return count;
+}
+
+/* ---- sub-receiver graph and bandscope ------------------------------------------------ */
+void qko_multirx_graph(qko_cd *samples, int data_width, double *out)
+{   /* get_multirx_graph, quisk.c:4478-4519; samples (8 * data_width of them) are overwritten */
+    const int mult = 8, N = data_width * mult;
+    int i, j, k;
+    double d1, d2, scale;
+    for (i = 0, j = -N / 2; i < N; i++, j++) samples[i] *= 0.5 + 0.5 * cos(2. * M_PI * j / N);
+    qko_fft(samples, N);
+    scale = log10(N) + 31.0 * log10(2.0);
+    scale *= 20.0;
+    j = mult; k = 0; d1 = 0;
+    for (i = N / 2; i < N; i++) {
+        d1 += cabs(samples[i]);
+        if (--j == 0) { d2 = 20.0 * log10(d1) - scale; if (d2 < -200) d2 = -200; out[k++] = d2; d1 = 0; j = mult; }
+    }
+    for (i = 0; i < N / 2; i++) {
+        d1 += cabs(samples[i]);
+        if (--j == 0) { d2 = 20.0 * log10(d1) - scale; if (d2 < -200) d2 = -200; out[k++] = d2; d1 = 0; j = mult; }
+    }
+}
+
+void qko_bscope_init(qko_bscope *b, int size)
+{   /* init_bandscope, quisk.c:2758-2775 */
+    int i, j;
+    memset(b, 0, sizeof *b);
+    b->size = size;
+    b->window = (double *)malloc((size_t)size * sizeof(double));
+    b->avg = (double *)calloc((size_t)size / 2 + 2, sizeof(double));
+    for (i = 0, j = -size / 2; i < size; i++, j++) b->window[i] = 0.5 + 0.5 * cos(2. * M_PI * j / size);
+}
+void qko_bscope_free(qko_bscope *b) { free(b->window); free(b->avg); memset(b, 0, sizeof *b); }
+void qko_bscope_add(qko_bscope *b, const double *samples)
+{   /* the processing half of get_bandscope, quisk.c:4545-4558 (the r2c transform as a complex one) */
+    int i, L = b->size / 2 + 1;
+    qko_cd *x = (qko_cd *)malloc((size_t)b->size * sizeof(qko_cd));
+    for (i = 0; i < b->size; i++) {
+        double d1 = fabs(samples[i]);
+        if (d1 > b->the_max) b->the_max = d1;
+        x[i] = samples[i] * b->window[i];
+    }
+    qko_fft(x, b->size);
+    for (i = 0; i < L; i++) b->avg[i] += cabs(x[i]);
+    b->count++;
+    free(x);
+}
+int qko_bscope_release(qko_bscope *b, int clock, double zoom, double deltaf, double *out, int graph_width, double *adc_level)
+{   /* quisk.c:4559-4595 */
+    int i, j, j1, j2, L = b->size / 2 + 1, count = b->count;
+    double frac, scale, rate, f1, d1, d2, sample;
+    if (count <= 0) return 0;
+    b->avg[L] = 0.0;
+    frac = (double)L / graph_width;
+    scale = 1.0 / frac / count / b->size;
+    rate = clock / 2.0;
+    for (i = 0; i < graph_width; i++) {
+        f1 = deltaf + rate / 2.0 * (1.0 - zoom);
+        d1 = L / rate * (f1 + (double)i / graph_width * zoom * rate);
+        d2 = L / rate * (f1 + (double)(i + 1) / graph_width * zoom * rate);
+        j1 = (int)floor(d1);
+        j2 = (int)floor(d2);
+#define BS_AT(j) (((j) >= 0 && (j) <= L) ? b->avg[j] : 0.0)     /* the reference indexes without a check */
+        if (j1 == j2) sample = (d2 - d1) * BS_AT(j1);
+        else {
+            sample = (j1 + 1 - d1) * BS_AT(j1);
+            for (j = j1 + 1; j < j2; j++) sample += BS_AT(j);
+            sample += (d2 - j2) * BS_AT(j2);
+        }
+#undef BS_AT
+        sample = sample * scale;
+        out[i] = sample <= 1E-10 ? -200.0 : 20.0 * log10(sample);
+    }
+    if (adc_level) *adc_level = b->the_max;
+    b->the_max = 0; b->count = 0;
+    for (i = 0; i < L; i++) b->avg[i] = 0;
     return count;
 }

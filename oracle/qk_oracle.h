@@ -110,7 +110,7 @@ void qko_fracdecim_init(qko_fracstate *s);
 int  qko_fracdecim(qko_fracstate *s, qko_cd *x, int n, double fdecim);  /* quisk.c:570-613 */
 
 /* ---- quisk.c: display spectrum --------------------------------------------------- */
-void qko_fft(qko_cd *x, int n);               /* forward complex DFT in place, n a power of two */
+void qko_fft(qko_cd *x, int n);               /* forward complex DFT in place, any n (radix 2 for powers of two) */
 void qko_hann_window(double *w, int n);       /* quisk.c:5091-5096 */
 typedef struct {
     int fft_size, data_width, sample_rate; double *window; double *avg; int count; double meter;
@@ -124,6 +124,15 @@ void qko_graph_add_frame(qko_graph *g, qko_cd *frame);
 /* release (quisk.c:4713-4753): pixel binning, dB scaling; returns the averaged-frame count, resets the average.
  * out has data_width doubles; *smeter receives the S-meter value (quisk.c:4728-4737). */
 int qko_graph_release(qko_graph *g, double zoom, double deltaf, double *out, double *smeter);
+
+/* get_multirx_graph (quisk.c:4468-4530): 8 * data_width samples (overwritten) -> data_width dB values */
+void qko_multirx_graph(qko_cd *samples, int data_width, double *out);
+/* bandscope: init_bandscope (quisk.c:2758-2775), get_bandscope (quisk.c:4532-4600) split into its two halves */
+typedef struct { int size, count; double *window, *avg; double the_max; } qko_bscope;
+void qko_bscope_init(qko_bscope *b, int size);
+void qko_bscope_free(qko_bscope *b);
+void qko_bscope_add(qko_bscope *b, const double *samples);
+int  qko_bscope_release(qko_bscope *b, int clock, double zoom, double deltaf, double *out, int graph_width, double *adc_level);
 
 /* ---- batch driver used as the timed CPU baseline --------------------------------- */
 /* run nrx receivers (already configured) over the same input block; audio of receiver r is written to

@@ -82,6 +82,9 @@ constexpr int FT_NTH = 128, FT_R = 5;      // k_fir_tiled / k_rxf_tiled: lanes p
 
 }  // namespace
 
+struct FftPlan;
+struct Bluestein;
+struct AnyFft;
 struct qk_engine {
     qk_config cfg{};
     std::mutex mu;
@@ -137,6 +140,13 @@ struct qk_engine {
     double *d_window = nullptr, *d_fft_avg = nullptr, *d_band = nullptr, *d_meter = nullptr, *d_graph = nullptr, *d_pix = nullptr;
     int *d_k0 = nullptr;
     int band_cap = 0;
+    Bluestein *blue = nullptr;             // display spectrum of a size that is not a power of two
+    // sub-receiver graphs (get_multirx_graph) and bandscope (get_bandscope): transforms made on first use
+    AnyFft *mrx = nullptr; int mrx_width = 0;
+    double2 *d_mrx_in = nullptr, *d_mrx_X = nullptr; double *d_mrx_out = nullptr;
+    AnyFft *bs = nullptr; int bs_size = 0, bs_count = 0, bs_out_cap = 0;
+    double *d_bs_in = nullptr, *d_bs_avg = nullptr, *d_bs_out = nullptr; double2 *d_bs_X = nullptr;
+    unsigned long long *d_bs_max = nullptr;
     double smeter = -160.0 + 4.25969;
     // stats / timing
     qk_stats stats{};
@@ -625,6 +635,12 @@ static int engine_init(qk_engine *e)
         f->hp = e->d_coefs + reinterpret_cast<size_t>(f->hp);
 #undef FIX
     int rc = QK_OK;
+    {
+        std::vector<double2> tw(4096);
+        for (int j = 0; j < 4096; j++) tw[j] = make_double2(cos(2.0 * M_PI * j / 4096), -sin(2.0 * M_PI * j / 4096));
+        HIPCHECK(hipMalloc(&e->d_tw4096, sizeof(double2) * 4096));
+        HIPCHECK(hipMemcpy(e->d_tw4096, tw.data(), sizeof(double2) * 4096, hipMemcpyHostToDevice));
+    }
     HIPCHECK(hipMalloc(&e->d_in, (size_t)cfg.max_block * sizeof(double2)));
     if (e->nrx > 0) { rc = init_receivers(e); if (rc != QK_OK) return rc; }
     if (cfg.fft_size > 0) { rc = init_spectrum(e); if (rc != QK_OK) return rc; }
@@ -673,33 +689,188 @@ struct Timer {      // bucket 0..7 = QK_KT_*, 8 = whole block
 static inline dim3 grid1(int n, int planes, int nz) { return dim3((unsigned)((n + 255) / 256), (unsigned)planes, (unsigned)nz); }
 
 
+// ---------------------------------------------------------------------------------- generic FFT plans
+struct FftPlan {       // power-of-two complex FFT of M points in HBM (k_gfft_*)
+    int M = 0, N1 = 1;
+    double2 *tw_lo = nullptr, *tw_hi = nullptr, *Y = nullptr;
+};
+struct Bluestein {     // any length N through two FFTs of M >= 2N - 1 points
+    int N = 0, M = 0;
+    FftPlan plan;
+    double2 *pre = nullptr;     // window[n] * chirp[n]  (or the chirp alone)
+    double2 *chirp = nullptr;   // c[k] = exp(-i pi k^2 / N), k < N
+    double2 *Bhat = nullptr;    // FFT_M of conj(c) wrapped
+    double2 *work = nullptr;    // M
+};
+static bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+static void plan_free(FftPlan &p)
+{
+    if (p.tw_lo) hipFree(p.tw_lo);
+    if (p.tw_hi) hipFree(p.tw_hi);
+    if (p.Y) hipFree(p.Y);
+    p = FftPlan();
+}
+static int plan_init(FftPlan &p, int M)
+{
+    if (!is_pow2(M) || M < 64 || M > (1 << 24)) return fail(QK_EUNSUPPORTED, "FFT plan: size out of range");
+    p.M = M; p.N1 = M > 4096 ? M / 4096 : 1;
+    if (p.N1 > 1) {
+        std::vector<double2> lo(1024), hi(std::max(1, M / 1024));
+        for (int j = 0; j < 1024; j++) lo[j] = make_double2(cos(2.0 * M_PI * j / M), -sin(2.0 * M_PI * j / M));
+        for (size_t j = 0; j < hi.size(); j++) {
+            const double t = 2.0 * M_PI * (double)j * 1024.0 / M;
+            hi[j] = make_double2(cos(t), -sin(t));
+        }
+        HIPCHECK(hipMalloc(&p.tw_lo, sizeof(double2) * lo.size()));
+        HIPCHECK(hipMemcpy(p.tw_lo, lo.data(), sizeof(double2) * lo.size(), hipMemcpyHostToDevice));
+        HIPCHECK(hipMalloc(&p.tw_hi, sizeof(double2) * hi.size()));
+        HIPCHECK(hipMemcpy(p.tw_hi, hi.data(), sizeof(double2) * hi.size(), hipMemcpyHostToDevice));
+        HIPCHECK(hipMalloc(&p.Y, sizeof(double2) * M));
+    }
+    return QK_OK;
+}
+// out[k] (k < n_out) = FFT_M or M-scaled inverse of in[e] (e < n_in, zero beyond), with the fused element-wise steps
+static void gfft_run(qk_engine *e, const FftPlan &p, hipStream_t st, const double2 *in, const double *in_real, int n_in,
+                     double2 *out, int n_out, const double2 *pre, const double2 *post, bool inverse)
+{
+    GfftArgs a{};
+    a.in = in; a.in_real = in_real; a.out = out; a.Y = p.Y; a.pre = pre; a.post = post;
+    a.tw4096 = e->d_tw4096; a.tw_lo = p.tw_lo; a.tw_hi = p.tw_hi;
+    a.M = p.M; a.N1 = p.N1; a.n_in = n_in; a.n_out = n_out; a.inverse = inverse ? 1 : 0; a.scale = 1.0 / p.M;
+    if (p.N1 > 1) {
+        hipLaunchKernelGGL(k_gfft_cols, dim3(p.N1), dim3(FFT_BIG_THREADS), 0, st, a);
+        hipLaunchKernelGGL(k_gfft_rows, dim3(p.N1), dim3(FFT_BIG_THREADS), 0, st, a);
+        return;
+    }
+    switch (p.M) {
+    case 64: hipLaunchKernelGGL(k_gfft_small<64>, dim3(1), dim3(FFT_THREADS), 0, st, a); break;
+    case 128: hipLaunchKernelGGL(k_gfft_small<128>, dim3(1), dim3(FFT_THREADS), 0, st, a); break;
+    case 256: hipLaunchKernelGGL(k_gfft_small<256>, dim3(1), dim3(FFT_THREADS), 0, st, a); break;
+    case 512: hipLaunchKernelGGL(k_gfft_small<512>, dim3(1), dim3(FFT_THREADS), 0, st, a); break;
+    case 1024: hipLaunchKernelGGL(k_gfft_small<1024>, dim3(1), dim3(FFT_THREADS), 0, st, a); break;
+    case 2048: hipLaunchKernelGGL(k_gfft_small<2048>, dim3(1), dim3(FFT_THREADS), 0, st, a); break;
+    default: hipLaunchKernelGGL(k_gfft_small<4096>, dim3(1), dim3(FFT_THREADS), 0, st, a); break;
+    }
+}
+
+static void blue_free(Bluestein *&b)
+{
+    if (!b) return;
+    plan_free(b->plan);
+    for (void *p : {(void *)b->pre, (void *)b->chirp, (void *)b->Bhat, (void *)b->work}) if (p) hipFree(p);
+    delete b; b = nullptr;
+}
+// window: N doubles on the host, or nullptr for none
+static int blue_init(qk_engine *e, Bluestein *&out, int N, const double *window)
+{
+    if (N < 2 || N > (1 << 23)) return fail(QK_EUNSUPPORTED, "FFT size out of range");
+    Bluestein *b = new (std::nothrow) Bluestein();
+    if (!b) return fail(QK_ENOMEM, "out of host memory");
+    out = b;
+    b->N = N;
+    int M = 64;
+    while (M < 2 * N - 1) M <<= 1;
+    b->M = M;
+    int rc = plan_init(b->plan, M);
+    if (rc != QK_OK) return rc;
+    std::vector<double2> c(N), pre(N), bw((size_t)M, make_double2(0.0, 0.0));
+    for (long long n = 0; n < N; n++) {
+        const long long r = (n * n) % (2LL * N);                 // the phase pi n^2 / N, reduced exactly
+        const double ang = M_PI * (double)r / (double)N;
+        c[n] = make_double2(cos(ang), -sin(ang));
+        const double w = window ? window[n] : 1.0;
+        pre[n] = make_double2(c[n].x * w, c[n].y * w);
+        const double2 cc = make_double2(c[n].x, -c[n].y);        // conj(c[n]) at lags +n and -n
+        bw[n] = cc;
+        if (n) bw[M - n] = cc;
+    }
+    HIPCHECK(hipMalloc(&b->chirp, sizeof(double2) * N));
+    HIPCHECK(hipMemcpy(b->chirp, c.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&b->pre, sizeof(double2) * N));
+    HIPCHECK(hipMemcpy(b->pre, pre.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&b->Bhat, sizeof(double2) * M));
+    HIPCHECK(hipMalloc(&b->work, sizeof(double2) * M));
+    HIPCHECK(hipMemcpy(b->work, bw.data(), sizeof(double2) * M, hipMemcpyHostToDevice));
+    gfft_run(e, b->plan, e->fe_stream, b->work, nullptr, M, b->Bhat, M, nullptr, nullptr, false);
+    HIPCHECK(hipStreamSynchronize(e->fe_stream));
+    return QK_OK;
+}
+// X[k], k < N, natural order, of x[n] (complex, or real when x_real is given) times the plan's window
+static void blue_run(qk_engine *e, Bluestein *b, hipStream_t st, const double2 *x, const double *x_real, double2 *X)
+{
+    gfft_run(e, b->plan, st, x, x_real, b->N, b->work, b->M, b->pre, b->Bhat, false);
+    gfft_run(e, b->plan, st, b->work, nullptr, b->M, X, b->N, nullptr, b->chirp, true);
+}
+
+// a windowed forward transform of any length: the plain plan for powers of two, Bluestein otherwise
+struct AnyFft {
+    int N = 0;
+    FftPlan plan; bool use_plan = false;
+    Bluestein *blue = nullptr;
+    double2 *winc = nullptr;    // the window as complex numbers (plan path: fused into the load)
+};
+static void any_free(AnyFft *&f)
+{
+    if (!f) return;
+    plan_free(f->plan);
+    blue_free(f->blue);
+    if (f->winc) hipFree(f->winc);
+    delete f; f = nullptr;
+}
+static int any_init(qk_engine *e, AnyFft *&out, int N, const double *window)
+{
+    AnyFft *f = new (std::nothrow) AnyFft();
+    if (!f) return fail(QK_ENOMEM, "out of host memory");
+    out = f;
+    f->N = N;
+    if (is_pow2(N) && N >= 64) {
+        f->use_plan = true;
+        int rc = plan_init(f->plan, N);
+        if (rc != QK_OK) return rc;
+        std::vector<double2> wc(N);
+        for (int i = 0; i < N; i++) wc[i] = make_double2(window ? window[i] : 1.0, 0.0);
+        HIPCHECK(hipMalloc(&f->winc, sizeof(double2) * N));
+        HIPCHECK(hipMemcpy(f->winc, wc.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+        return QK_OK;
+    }
+    return blue_init(e, f->blue, N, window);
+}
+static void any_run(qk_engine *e, AnyFft *f, hipStream_t st, const double2 *x, const double *x_real, double2 *X)
+{
+    if (f->use_plan) gfft_run(e, f->plan, st, x, x_real, f->N, X, f->N, f->winc, nullptr, false);
+    else blue_run(e, f->blue, st, x, x_real, X);
+}
+
 // ---------------------------------------------------------------------------------- display spectrum
 static int init_spectrum(qk_engine *e)
 {
     const int N = e->cfg.fft_size, W = e->cfg.data_width;
-    if (N < 64 || (N & (N - 1))) return fail(QK_EUNSUPPORTED, "fft_size must be a power of two >= 64 (mixed-radix sizes: not yet)");
+    if (N < 2 || N > (1 << 24)) return fail(QK_EUNSUPPORTED, "fft_size out of range (2 ... 2^24)");
     if (W < 1 || W > N) return fail(QK_EINVAL, "data_width must be in [1, fft_size]");
-    e->fftN = N; e->fftW = W; e->fftN1 = N > 4096 ? N / 4096 : 1;
-    if (e->fftN1 > 4096) return fail(QK_EUNSUPPORTED, "fft_size above 2^24");
+    const bool direct = is_pow2(N) && N >= 64;          // anything else goes through Bluestein (quisk.py:3858-3890 sizes)
+    e->fftN = N; e->fftW = W; e->fftN1 = direct && N > 4096 ? N / 4096 : 1;
     std::vector<double> win(N);
     for (int i = 0, j = -N / 2; i < N; i++, j++) win[i] = 0.5 + 0.5 * cos(2. * M_PI * j / N);   // quisk.c:5091-5096
-    std::vector<double2> tw(4096), lo(1024), hi(std::max(1, N / 1024));
-    for (int j = 0; j < 4096; j++) tw[j] = make_double2(cos(2.0 * M_PI * j / 4096), -sin(2.0 * M_PI * j / 4096));
-    for (int j = 0; j < 1024; j++) lo[j] = make_double2(cos(2.0 * M_PI * j / N), -sin(2.0 * M_PI * j / N));
-    for (size_t j = 0; j < hi.size(); j++) {
-        const double t = 2.0 * M_PI * (double)j * 1024.0 / N;
-        hi[j] = make_double2(cos(t), -sin(t));
-    }
     HIPCHECK(hipMalloc(&e->d_window, sizeof(double) * N));
     HIPCHECK(hipMemcpy(e->d_window, win.data(), sizeof(double) * N, hipMemcpyHostToDevice));
-    HIPCHECK(hipMalloc(&e->d_tw4096, sizeof(double2) * 4096));
-    HIPCHECK(hipMemcpy(e->d_tw4096, tw.data(), sizeof(double2) * 4096, hipMemcpyHostToDevice));
-    HIPCHECK(hipMalloc(&e->d_tw_lo, sizeof(double2) * 1024));
-    HIPCHECK(hipMemcpy(e->d_tw_lo, lo.data(), sizeof(double2) * 1024, hipMemcpyHostToDevice));
-    HIPCHECK(hipMalloc(&e->d_tw_hi, sizeof(double2) * hi.size()));
-    HIPCHECK(hipMemcpy(e->d_tw_hi, hi.data(), sizeof(double2) * hi.size(), hipMemcpyHostToDevice));
+    if (direct) {
+        std::vector<double2> lo(1024), hi(std::max(1, N / 1024));
+        for (int j = 0; j < 1024; j++) lo[j] = make_double2(cos(2.0 * M_PI * j / N), -sin(2.0 * M_PI * j / N));
+        for (size_t j = 0; j < hi.size(); j++) {
+            const double t = 2.0 * M_PI * (double)j * 1024.0 / N;
+            hi[j] = make_double2(cos(t), -sin(t));
+        }
+        HIPCHECK(hipMalloc(&e->d_tw_lo, sizeof(double2) * 1024));
+        HIPCHECK(hipMemcpy(e->d_tw_lo, lo.data(), sizeof(double2) * 1024, hipMemcpyHostToDevice));
+        HIPCHECK(hipMalloc(&e->d_tw_hi, sizeof(double2) * hi.size()));
+        HIPCHECK(hipMemcpy(e->d_tw_hi, hi.data(), sizeof(double2) * hi.size(), hipMemcpyHostToDevice));
+    } else {
+        int rcb = blue_init(e, e->blue, N, win.data());
+        if (rcb != QK_OK) return rcb;
+    }
     HIPCHECK(hipMalloc(&e->d_fft_stage, sizeof(double2) * N));
-    if (e->fftN1 > 1) HIPCHECK(hipMalloc(&e->d_fft_Y, sizeof(double2) * N));
+    if (e->fftN1 > 1 || e->blue) HIPCHECK(hipMalloc(&e->d_fft_Y, sizeof(double2) * N));
     HIPCHECK(hipMalloc(&e->d_fft_avg, sizeof(double) * N));
     HIPCHECK(hipMemset(e->d_fft_avg, 0, sizeof(double) * N));
     e->band_cap = N / 2 + 2;
@@ -730,7 +901,10 @@ static void fft_frame(qk_engine *e, const double2 *frame)
     const bool meter_on = bw > 0 && (i0 > -N / 2 && i0 + nw + 1 < N / 2) && nw + 1 <= e->band_cap;
     a.band_start = i0; a.band_count = meter_on ? nw + 1 : 0;
     Timer tm(e, QK_KT_FFT, e->fe_stream);
-    if (e->fftN1 > 1) {
+    if (e->blue) {
+        blue_run(e, e->blue, e->fe_stream, frame, nullptr, e->d_fft_Y);
+        hipLaunchKernelGGL(k_graph_accum, dim3((N + 255) / 256), dim3(256), 0, e->fe_stream, e->d_fft_Y, a);
+    } else if (e->fftN1 > 1) {
         hipLaunchKernelGGL(k_fft_cols, dim3(e->fftN1), dim3(FFT_BIG_THREADS), 0, e->fe_stream, a);
         hipLaunchKernelGGL(k_fft_rows, dim3(e->fftN1), dim3(FFT_BIG_THREADS), 0, e->fe_stream, a);
     } else {
@@ -1142,6 +1316,12 @@ void qk_destroy(qk_engine *e)
     if (e->agc_stream) hipStreamSynchronize(e->agc_stream);
     free_chain(e->front);
     for (auto &c : e->cls_chain) free_chain(c);
+    blue_free(e->blue);
+    any_free(e->mrx);
+    any_free(e->bs);
+    for (void *p : {(void *)e->d_mrx_in, (void *)e->d_mrx_X, (void *)e->d_mrx_out, (void *)e->d_bs_in, (void *)e->d_bs_avg,
+                    (void *)e->d_bs_out, (void *)e->d_bs_X, (void *)e->d_bs_max})
+        if (p) hipFree(p);
     for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
     void *ptrs[] = {e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps,
                     e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_out,
@@ -1326,6 +1506,127 @@ int qk_get_graph(qk_engine *e, double zoom, double deltaf, double *out, int data
 int qk_graph_pending(qk_engine *e) { ENGINE_ENTER(e); return e->fft_count; }
 int qk_graph_device(qk_engine *e, const double **dev_ptr) { ENGINE_ENTER(e); if (dev_ptr) *dev_ptr = e->d_graph; return QK_OK; }
 double qk_get_smeter(qk_engine *e) { return e ? e->smeter : 0.0; }
+
+int qk_multirx_graph(qk_engine *e, const double *iq_host, int data_width, double *out)
+{
+    ENGINE_ENTER(e);
+    if (!iq_host || !out || data_width < 1 || data_width > (1 << 20)) return fail(QK_EINVAL, "bad multirx graph arguments");
+    const int mult = 8;                                  // MULTIRX_FFT_MULT, quisk.c:32
+    const int N = data_width * mult;                     // multirx_fft_width, quisk.c:5098
+    if (e->mrx_width != data_width) {
+        HIPCHECK(hipStreamSynchronize(e->fe_stream));
+        any_free(e->mrx);
+        for (void *p : {(void *)e->d_mrx_in, (void *)e->d_mrx_X, (void *)e->d_mrx_out}) if (p) hipFree(p);
+        e->d_mrx_in = e->d_mrx_X = nullptr; e->d_mrx_out = nullptr; e->mrx_width = 0;
+        std::vector<double> win(N);
+        for (int i = 0, j = -N / 2; i < N; i++, j++) win[i] = 0.5 + 0.5 * cos(2. * M_PI * j / N);     // quisk.c:4481-4482
+        int rc = any_init(e, e->mrx, N, win.data());
+        if (rc != QK_OK) return rc;
+        HIPCHECK(hipMalloc(&e->d_mrx_in, sizeof(double2) * N));
+        HIPCHECK(hipMalloc(&e->d_mrx_X, sizeof(double2) * N));
+        HIPCHECK(hipMalloc(&e->d_mrx_out, sizeof(double) * data_width));
+        e->mrx_width = data_width;
+    }
+    hipStream_t st = e->fe_stream;
+    HIPCHECK(hipMemcpyAsync(e->d_mrx_in, iq_host, sizeof(double2) * N, hipMemcpyHostToDevice, st));
+    any_run(e, e->mrx, st, e->d_mrx_in, nullptr, e->d_mrx_X);
+    const double scale = 20.0 * (log10((double)N) + 31.0 * log10(2.0));      // quisk.c:4493-4494
+    hipLaunchKernelGGL(k_multirx_bins, dim3((data_width + 255) / 256), dim3(256), 0, st, e->d_mrx_X, N, mult, data_width, scale, e->d_mrx_out);
+    HIPCHECK(hipMemcpyAsync(out, e->d_mrx_out, sizeof(double) * data_width, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    HIPCHECK(hipGetLastError());
+    return QK_OK;
+}
+
+int qk_bandscope_init(qk_engine *e, int size)
+{
+    ENGINE_ENTER(e);
+    if (size < 2 || size > (1 << 22)) return fail(QK_EINVAL, "bad bandscope size");
+    HIPCHECK(hipStreamSynchronize(e->fe_stream));
+    any_free(e->bs);
+    for (void *p : {(void *)e->d_bs_in, (void *)e->d_bs_avg, (void *)e->d_bs_X, (void *)e->d_bs_max}) if (p) hipFree(p);
+    e->d_bs_in = e->d_bs_avg = nullptr; e->d_bs_X = nullptr; e->d_bs_max = nullptr; e->bs_size = 0; e->bs_count = 0;
+    std::vector<double> win(size);
+    for (int i = 0, j = -size / 2; i < size; i++, j++) win[i] = 0.5 + 0.5 * cos(2. * M_PI * j / size);   // quisk.c:2769-2770
+    int rc = any_init(e, e->bs, size, win.data());
+    if (rc != QK_OK) return rc;
+    const int L = size / 2 + 1;
+    HIPCHECK(hipMalloc(&e->d_bs_in, sizeof(double) * size));
+    HIPCHECK(hipMalloc(&e->d_bs_X, sizeof(double2) * size));
+    HIPCHECK(hipMalloc(&e->d_bs_avg, sizeof(double) * (L + 1)));
+    HIPCHECK(hipMemset(e->d_bs_avg, 0, sizeof(double) * (L + 1)));
+    HIPCHECK(hipMalloc(&e->d_bs_max, sizeof(unsigned long long)));
+    HIPCHECK(hipMemset(e->d_bs_max, 0, sizeof(unsigned long long)));
+    e->bs_size = size;
+    return QK_OK;
+}
+
+int qk_add_bscope_samples(qk_engine *e, const double *samples_host, int n)
+{
+    ENGINE_ENTER(e);
+    if (e->bs_size <= 0) return fail(QK_EINVAL, "The bandscope was not initialized");        // quisk.c:2851-2855
+    if (!samples_host || n != e->bs_size) return fail(QK_EINVAL, "Wrong number of samples in bandscope block");
+    hipStream_t st = e->fe_stream;
+    const int L = n / 2 + 1;
+    HIPCHECK(hipMemcpyAsync(e->d_bs_in, samples_host, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_absmax, dim3(std::min(64, (n + 255) / 256)), dim3(256), 0, st, e->d_bs_in, n, e->d_bs_max);
+    any_run(e, e->bs, st, nullptr, e->d_bs_in, e->d_bs_X);
+    hipLaunchKernelGGL(k_bscope_accum, dim3((L + 255) / 256), dim3(256), 0, st, e->d_bs_X, L, e->d_bs_avg);
+    HIPCHECK(hipStreamSynchronize(st));          // the host buffer may be reused at once, as in the reference
+    HIPCHECK(hipGetLastError());
+    e->bs_count++;
+    return QK_OK;
+}
+
+int qk_add_bscope_samples_int(qk_engine *e, const void *raw, size_t n_bytes, int bytes, int big_endian)
+{
+    if (!e) return fail(QK_EINVAL, "null engine");
+    if (bytes < 1 || bytes > 4 || !raw) return fail(QK_EINVAL, "bad bandscope sample format");
+    if (e->bs_size <= 0) return fail(QK_EINVAL, "The bandscope was not initialized");
+    if (n_bytes != (size_t)e->bs_size * bytes) return fail(QK_EINVAL, "Wrong number of bytes in sample buffer");   // quisk.c:2867
+    // a few KiB per block: unpacked on the host (left-justified into int32, then / CLIP32, quisk.c:2870-2895)
+    std::vector<double> v((size_t)e->bs_size);
+    const unsigned char *p = static_cast<const unsigned char *>(raw);
+    for (int i = 0; i < e->bs_size; i++, p += bytes) {
+        uint32_t u = 0;
+        for (int b = 0; b < bytes; b++) {
+            const int sig = big_endian ? (bytes - 1 - b) : b;
+            u |= (uint32_t)p[b] << (8 * (4 - bytes + sig));
+        }
+        v[i] = (double)(int32_t)u / QK_CLIP32;
+    }
+    return qk_add_bscope_samples(e, v.data(), e->bs_size);
+}
+
+int qk_get_bandscope(qk_engine *e, int clock, double zoom, double deltaf, double *out, int graph_width, double *adc_level)
+{
+    ENGINE_ENTER(e);
+    if (e->bs_size <= 0) return fail(QK_EINVAL, "The bandscope was not initialized");
+    if (!out || graph_width < 1 || clock <= 0) return fail(QK_EINVAL, "bad bandscope arguments");
+    const int count = e->bs_count;
+    if (count <= 0) return 0;
+    hipStream_t st = e->fe_stream;
+    if (graph_width > e->bs_out_cap) {
+        HIPCHECK(hipStreamSynchronize(st));
+        if (e->d_bs_out) hipFree(e->d_bs_out);
+        e->d_bs_out = nullptr; e->bs_out_cap = 0;
+        HIPCHECK(hipMalloc(&e->d_bs_out, sizeof(double) * graph_width));
+        e->bs_out_cap = graph_width;
+    }
+    const int L = e->bs_size / 2 + 1;
+    const double frac = (double)L / graph_width;
+    BscopeRelease a{e->d_bs_avg, e->d_bs_out, L, graph_width, zoom, deltaf, clock / 2.0, 1.0 / frac / count / e->bs_size};
+    hipLaunchKernelGGL(k_bscope_release, dim3((graph_width + 255) / 256), dim3(256), 0, st, a);
+    unsigned long long mx = 0;
+    HIPCHECK(hipMemcpyAsync(out, e->d_bs_out, sizeof(double) * graph_width, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemcpyAsync(&mx, e->d_bs_max, sizeof mx, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipMemsetAsync(e->d_bs_avg, 0, sizeof(double) * (L + 1), st));
+    HIPCHECK(hipMemsetAsync(e->d_bs_max, 0, sizeof mx, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    if (adc_level) { double d; memcpy(&d, &mx, sizeof d); *adc_level = d; }     // hermes_adc_level, quisk.c:4591
+    e->bs_count = 0;
+    return count;
+}
 
 int qk_get_filter_rate(int sample_rate, int mode, int bandwidth) { return filter_rate(sample_rate, mode, bandwidth); }
 int qk_plan_decimation(int sample_rate, int *d2, int *d3, int *d5) { return plan_decimation(sample_rate, d2, d3, d5); }

@@ -186,7 +186,8 @@ struct ReleaseArgs {
 };
 __device__ __forceinline__ double avg_at(const ReleaseArgs &a, int kk)
 {
-    const int k = (kk + a.N / 2) & (a.N - 1);
+    int k = kk + a.N / 2;
+    if (k >= a.N) k -= a.N;
     const int k1 = k % a.N1, k2 = k / a.N1;
     return a.avg[(long long)k1 * (a.N / a.N1) + k2];
 }
@@ -236,4 +237,143 @@ __global__ __launch_bounds__(256) void k_graph_release_inplace(ReleaseArgs a, do
         if (d < -200) d = -200;
         a.out[i] = d;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic power-of-two complex FFT in HBM, natural order in and out, with the element-wise steps of its
+// callers fused into the load and the store.  It serves the spectra that are not the 2^k display FFT: any
+// other fft_size (Quisk's fft_size = data_width * fft_mult has factors 3, 5, 7 ..., quisk.py:3858-3890), the
+// sub-receiver graphs (get_multirx_graph, quisk.c:4468-4530: 8 * multirx_data_width points) and the bandscope
+// (get_bandscope, quisk.c:4532-4600).  A length N that is not a power of two goes through Bluestein's
+// identity  X[k] = c[k] * sum_n (x[n] c[n]) conj(c[k-n]),  c[n] = exp(-i pi n^2 / N):  one forward and one
+// inverse FFT of M >= 2N-1 points; the chirp and the transformed kernel are made once per size on the host
+// (n^2 reduced mod 2N in integers, so the phases are exact to the last bit of cos/sin).
+//   load :  v = in[e] (zero for e >= n_in; a real input has zero imaginary part); v *= pre[e]; inverse: conj
+//   store:  inverse: conj and scale; r *= post[k]; stored for k < n_out
+// M <= 4096 runs in one workgroup; larger M is the four-step above with M = N1 x 4096 and a strided final store.
+// ------------------------------------------------------------------------------------------------
+struct GfftArgs {
+    const double2 *in; const double *in_real; double2 *out; double2 *Y;
+    const double2 *pre, *post;
+    const double2 *tw4096, *tw_lo, *tw_hi;
+    int M, N1, n_in, n_out, inverse;
+    double scale;
+};
+__device__ __forceinline__ double2 gfft_load(const GfftArgs &a, int e)
+{
+    double2 v = make_double2(0.0, 0.0);
+    if (e < a.n_in) {
+        v = a.in_real ? make_double2(a.in_real[e], 0.0) : a.in[e];
+        if (a.pre) v = cmul_d(v, a.pre[e]);
+        if (a.inverse) v.y = -v.y;
+    }
+    return v;
+}
+__device__ __forceinline__ void gfft_store(const GfftArgs &a, int k, double2 r)
+{
+    if (k >= a.n_out) return;
+    if (a.inverse) r = make_double2(r.x * a.scale, -r.y * a.scale);
+    if (a.post) r = cmul_d(r, a.post[k]);
+    a.out[k] = r;
+}
+template <int TOTAL>
+__global__ __launch_bounds__(FFT_THREADS) void k_gfft_small(GfftArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double2 buf[TOTAL];
+    for (int e = threadIdx.x; e < TOTAL; e += FFT_THREADS) buf[e] = gfft_load(a, e);
+    lds_fft<TOTAL>(buf, TOTAL, 1, a.tw4096);
+    for (int e = threadIdx.x; e < TOTAL; e += FFT_THREADS) gfft_store(a, e, buf[e]);
+}
+__global__ __launch_bounds__(FFT_BIG_THREADS) void k_gfft_cols(GfftArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double2 buf[4096];
+    const int N1 = a.N1, TW = 4096 / N1;
+    const int c0 = blockIdx.x * TW;
+    for (int e = threadIdx.x; e < 4096; e += FFT_BIG_THREADS) {
+        const int n1 = e / TW, col = e - n1 * TW;
+        buf[e] = gfft_load(a, n1 * 4096 + c0 + col);
+    }
+    lds_fft<4096, FFT_BIG_THREADS>(buf, N1, TW, a.tw4096);
+    for (int e = threadIdx.x; e < 4096; e += FFT_BIG_THREADS) {
+        const int k1 = e / TW, col = e - k1 * TW;
+        const int n2 = c0 + col;
+        const long long t = (long long)n2 * k1;
+        const double2 w = cmul_d(a.tw_hi[t >> 10], a.tw_lo[t & 1023]);
+        a.Y[(long long)k1 * 4096 + n2] = cmul_d(buf[e], w);
+    }
+}
+__global__ __launch_bounds__(FFT_BIG_THREADS) void k_gfft_rows(GfftArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double2 buf[4096];
+    const int k1 = blockIdx.x;
+    const double2 *row = a.Y + (long long)k1 * 4096;
+    for (int e = threadIdx.x; e < 4096; e += FFT_BIG_THREADS) buf[e] = row[e];
+    lds_fft<4096, FFT_BIG_THREADS>(buf, 4096, 1, a.tw4096);
+    for (int e = threadIdx.x; e < 4096; e += FFT_BIG_THREADS) gfft_store(a, k1 + a.N1 * e, buf[e]);
+}
+
+// get_graph's accumulation for a spectrum X[0..N) in natural order (quisk.c:4668-4680, 4703-4710).
+__global__ __launch_bounds__(256) void k_graph_accum(const double2 *X, FftArgs a)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < a.N) fft_epilogue(a, 0, e, X[e]);
+}
+
+// get_multirx_graph (quisk.c:4491-4519): pixel k sums the magnitudes of MULT consecutive bins in order of
+// frequency, starting at bin N/2 (the most negative frequency), then 20 log10 - scale, floor -200.
+__global__ __launch_bounds__(256) void k_multirx_bins(const double2 *X, int N, int mult, int width, double scale, double *out)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= width) return;
+    double d1 = 0.0;
+    for (int t = 0; t < mult; t++) {
+        int i = N / 2 + k * mult + t;
+        if (i >= N) i -= N;
+        const double2 v = X[i];
+        d1 += hypot(v.x, v.y);
+    }
+    double d2 = 20.0 * log10(d1) - scale;
+    if (d2 < -200) d2 = -200;
+    out[k] = d2;
+}
+
+// Bandscope (get_bandscope, quisk.c:4545-4556): largest |sample| of the frame (before the window), as the
+// ordered bit pattern of a non-negative double; and the magnitude accumulation of bins 0..L-1.
+__global__ __launch_bounds__(256) void k_absmax(const double *x, int n, unsigned long long *mx)
+{
+    double m = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const double v = fabs(x[i]); if (v > m) m = v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(m, o, 64); m = m < w ? w : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(mx, (unsigned long long)__double_as_longlong(m));
+}
+__global__ __launch_bounds__(256) void k_bscope_accum(const double2 *X, int L, double *avg)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < L) avg[i] += hypot(X[i].x, X[i].y);
+}
+// Release (quisk.c:4560-4588): pixel i integrates the average from d1 to d2 (fractional bins at both ends), scales
+// by 1 / frac / count / size, and converts to dB with the reference's 1e-10 floor.  avg[L] is zero ("in case we
+// run off the end").  One thread per pixel, the inner sum in the reference's order.
+struct BscopeRelease { const double *avg; double *out; int L, width; double zoom, deltaf, rate, scale; };
+__global__ __launch_bounds__(256) void k_bscope_release(BscopeRelease a)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.width) return;
+    const double f1 = a.deltaf + a.rate / 2.0 * (1.0 - a.zoom);
+    const double d1 = a.L / a.rate * (f1 + (double)i / a.width * a.zoom * a.rate);
+    const double d2 = a.L / a.rate * (f1 + (double)(i + 1) / a.width * a.zoom * a.rate);
+    const int j1 = (int)floor(d1), j2 = (int)floor(d2);
+    auto at = [&](int j) { return (j >= 0 && j <= a.L) ? a.avg[j] : 0.0; };   // the reference reads out of bounds there
+    double sample;
+    if (j1 == j2) {
+        sample = (d2 - d1) * at(j1);
+    } else {
+        sample = (j1 + 1 - d1) * at(j1);
+        for (int j = j1 + 1; j < j2; j++) sample += at(j);
+        sample += (d2 - j2) * at(j2);
+    }
+    sample = sample * a.scale;
+    a.out[i] = sample <= 1E-10 ? -200.0 : 20.0 * log10(sample);
 }

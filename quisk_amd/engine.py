@@ -60,6 +60,11 @@ def lib():
     L.qk_audio_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.qk_get_graph.argtypes = [vp, C.c_double, C.c_double, vp, C.c_int, dp]
     L.qk_graph_pending.argtypes = [vp]
+    L.qk_multirx_graph.argtypes = [vp, vp, C.c_int, vp]
+    L.qk_bandscope_init.argtypes = [vp, C.c_int]
+    L.qk_add_bscope_samples.argtypes = [vp, vp, C.c_int]
+    L.qk_add_bscope_samples_int.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int]
+    L.qk_get_bandscope.argtypes = [vp, C.c_int, C.c_double, C.c_double, vp, C.c_int, dp]
     L.qk_get_smeter.argtypes = [vp]
     L.qk_get_smeter.restype = C.c_double
     L.qk_graph_device.argtypes = [vp, C.POINTER(vp)]
@@ -205,6 +210,34 @@ class Engine:
         sm = C.c_double(0.0)
         n = _check(self.L.qk_get_graph(self.h, float(zoom), float(deltaf), out.ctypes.data, self.data_width, C.byref(sm)))
         return n, out, sm.value
+
+    def multirx_graph(self, iq, data_width):
+        """get_multirx_graph's transform of one sub-receiver frame: 8 * data_width complex samples -> dB row."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex128)
+        if len(iq) != 8 * data_width:
+            raise ValueError("a multirx frame is 8 * data_width samples")
+        out = np.empty(data_width, dtype=np.float64)
+        _check(self.L.qk_multirx_graph(self.h, iq.ctypes.data, int(data_width), out.ctypes.data))
+        return out
+
+    def bandscope_init(self, size):
+        _check(self.L.qk_bandscope_init(self.h, int(size)))
+
+    def add_bscope_samples(self, samples):
+        """One bandscope block: real samples scaled to +-1 (float64), or raw bytes via add_bscope_samples_int."""
+        v = np.ascontiguousarray(samples, dtype=np.float64)
+        _check(self.L.qk_add_bscope_samples(self.h, v.ctypes.data, len(v)))
+
+    def add_bscope_samples_int(self, raw, nbytes, big_endian=False):
+        buf = np.frombuffer(raw, dtype=np.uint8)
+        _check(self.L.qk_add_bscope_samples_int(self.h, buf.ctypes.data, len(buf), int(nbytes), int(bool(big_endian))))
+
+    def get_bandscope(self, clock, zoom, deltaf, graph_width):
+        """(count, dB row, adc_level); count == 0 means no data (get_bandscope returning None)."""
+        out = np.empty(graph_width, dtype=np.float64)
+        lvl = C.c_double(0.0)
+        n = _check(self.L.qk_get_bandscope(self.h, int(clock), float(zoom), float(deltaf), out.ctypes.data, int(graph_width), C.byref(lvl)))
+        return n, out, lvl.value
 
     def reset_stats(self):
         _check(self.L.qk_reset_stats(self.h))

@@ -56,6 +56,10 @@ class OGraph(C.Structure):
                 ("rx_tune", C.c_int), ("filter_start_offset", C.c_int), ("filter_bandwidth", C.c_int)]
 
 
+class OBscope(C.Structure):
+    _fields_ = [("size", C.c_int), ("count", C.c_int), ("window", c_dp), ("avg", c_dp), ("the_max", C.c_double)]
+
+
 _oracle = None
 
 
@@ -107,6 +111,11 @@ def oracle():
     L.qko_fracdecim_init.argtypes = [P(OFrac)]
     L.qko_fracdecim.argtypes = [P(OFrac), cdp, C.c_int, C.c_double]
     L.qko_fft.argtypes = [cdp, C.c_int]
+    L.qko_multirx_graph.argtypes = [cdp, C.c_int, ddp]
+    L.qko_bscope_init.argtypes = [P(OBscope), C.c_int]
+    L.qko_bscope_free.argtypes = [P(OBscope)]
+    L.qko_bscope_add.argtypes = [P(OBscope), ddp]
+    L.qko_bscope_release.argtypes = [P(OBscope), C.c_int, C.c_double, C.c_double, ddp, C.c_int, P(C.c_double)]
     L.qko_hann_window.argtypes = [ddp, C.c_int]
     L.qko_graph_init.argtypes = [P(OGraph), C.c_int, C.c_int, C.c_int]
     L.qko_graph_free.argtypes = [P(OGraph)]
@@ -265,3 +274,36 @@ class OracleGraph:
 
     def close(self):
         self.L.qko_graph_free(C.byref(self.g))
+
+
+def oracle_multirx_graph(iq, data_width):
+    """get_multirx_graph restated (quisk.c:4468-4530)."""
+    L = oracle()
+    x = np.array(iq, dtype=np.complex128, copy=True)
+    assert len(x) == 8 * data_width
+    out = np.zeros(data_width)
+    L.qko_multirx_graph(x, int(data_width), out)
+    return out
+
+
+class OracleBscope:
+    """init_bandscope / get_bandscope restated (quisk.c:2758-2775, 4532-4600)."""
+
+    def __init__(self, size):
+        self.L = oracle()
+        self.b = OBscope()
+        self.L.qko_bscope_init(C.byref(self.b), int(size))
+
+    def add(self, samples):
+        v = np.ascontiguousarray(samples, dtype=np.float64)
+        assert len(v) == self.b.size
+        self.L.qko_bscope_add(C.byref(self.b), v)
+
+    def release(self, clock, zoom, deltaf, graph_width):
+        out = np.zeros(graph_width)
+        lvl = C.c_double(0)
+        n = self.L.qko_bscope_release(C.byref(self.b), int(clock), float(zoom), float(deltaf), out, int(graph_width), C.byref(lvl))
+        return n, out, lvl.value
+
+    def close(self):
+        self.L.qko_bscope_free(C.byref(self.b))
