@@ -211,6 +211,10 @@ class Engine:
         n = _check(self.L.qk_get_graph(self.h, float(zoom), float(deltaf), out.ctypes.data, self.data_width, C.byref(sm)))
         return n, out, sm.value
 
+    def smeter(self):
+        """get_smeter (quisk.c:2737-2742): the value of the last graph release."""
+        return float(self.L.qk_get_smeter(self.h))
+
     def multirx_graph(self, iq, data_width):
         """get_multirx_graph's transform of one sub-receiver frame: 8 * data_width complex samples -> dB row."""
         iq = np.ascontiguousarray(iq, dtype=np.complex128)
