@@ -73,7 +73,10 @@ struct Chain {
     // fractional decimator (cFracDecim, quisk.c:570-613): the position recurrence runs on the host
     double frac_dindex = 1.0;
     int *d_frac_idx = nullptr; double *d_frac_pos = nullptr; int frac_cap = 0;
-    double *d_frac_state = nullptr;
+    // the positions of a block go to the device through a small ring of pinned staging buffers
+    struct FracSlot { int *idx = nullptr; double *pos = nullptr; hipEvent_t ev = nullptr; bool used = false; };
+    FracSlot frac_slot[4];
+    int frac_next = 0;
 };
 
 struct DevTables { std::vector<double> host; double *dev = nullptr; };
@@ -97,7 +100,7 @@ struct qk_engine {
     hipStream_t fe_stream = nullptr;
     hipStream_t agc_stream = nullptr;
     hipEvent_t ev_chain = nullptr, ev_agc[2] = {nullptr, nullptr};
-    hipEvent_t ev_fe = nullptr;                        // front end (and head copy) of this block done
+    hipEvent_t ev_fe = nullptr, ev_fe2 = nullptr;      // front end (and head copy) of this block done (alternating)
     hipEvent_t ev_read[2] = {nullptr, nullptr};        // the chains have finished reading front-stream twin q
     bool read_pending[2] = {false, false};
     int fe_blocks = 0;                                 // blocks in which the front end produced output (twin parity)
@@ -105,6 +108,8 @@ struct qk_engine {
     int nrx = 0, S = 0, tap_cap = DEFAULT_TAP_CAP;
     int fe_rate = 0, decim_srate = 0;
     int fe_slots = 2304;       // resident one-wave workgroups of k_frontend_wave on the whole chip (occupancy query)
+    int fe_share = 100;        // percent of the resident slots the front end may occupy (QK_FE_SHARE)
+    int fe_rounds = 2;         // front-end workgroups launched per resident slot (QK_FE_ROUNDS)
     int fe_variant = 1;        // 1 = k_frontend_wave (one wave per span), 0 = k_frontend (256-thread workgroups); QK_FE_VARIANT
     int rate_case = 0;
     // input
@@ -292,7 +297,11 @@ static void free_chain(Chain &c)
     if (c.front_alt) hipFree(c.front_alt);
     if (c.d_frac_idx) hipFree(c.d_frac_idx);
     if (c.d_frac_pos) hipFree(c.d_frac_pos);
-    if (c.d_frac_state) hipFree(c.d_frac_state);
+    for (auto &fs : c.frac_slot) {
+        if (fs.idx) hipHostFree(fs.idx);
+        if (fs.pos) hipHostFree(fs.pos);
+        if (fs.ev) hipEventDestroy(fs.ev);
+    }
     c = Chain();
 }
 
@@ -427,8 +436,12 @@ static int build_class(qk_engine *e, int cl)
         c.frac_cap = b.cur_cap + 8;
         HIPCHECK(hipMalloc(&c.d_frac_idx, sizeof(int) * c.frac_cap));
         HIPCHECK(hipMalloc(&c.d_frac_pos, sizeof(double) * c.frac_cap));
-        HIPCHECK(hipMalloc(&c.d_frac_state, sizeof(double)));
-        { const double one = 1.0; HIPCHECK(hipMemcpy(c.d_frac_state, &one, sizeof(double), hipMemcpyHostToDevice)); }   // dindex = 1 (quisk.c:575)
+        for (auto &fs : c.frac_slot) {
+            HIPCHECK(hipHostMalloc(&fs.idx, sizeof(int) * c.frac_cap, hipHostMallocMapped));
+            HIPCHECK(hipHostMalloc(&fs.pos, sizeof(double) * c.frac_cap, hipHostMallocMapped));
+            HIPCHECK(hipEventCreateWithFlags(&fs.ev, hipEventDisableTiming));
+        }
+        c.frac_dindex = 1.0;                                         // dindex = 1 (quisk.c:575)
     }
     // ... then interpolation to the play rate (quisk.c:2535-2553); mono, so one plane carries both channels
     for (int r = e->cfg.playback_rate / 48000; r > 1; r /= 2) b.hbint(1, T_B);
@@ -521,6 +534,8 @@ static int init_receivers(qk_engine *e)
     // mixer state
     e->H = (44 << e->S) + (1 << e->S) + 128;
     if (const char *v = getenv("QK_FE_VARIANT")) e->fe_variant = atoi(v) ? 1 : 0;
+    if (const char *v = getenv("QK_FE_SHARE")) e->fe_share = std::max(5, std::min(100, atoi(v)));
+    if (const char *v = getenv("QK_FE_ROUNDS")) e->fe_rounds = std::max(1, std::min(16, atoi(v)));
     {
         int per_cu = 0, cus = 256;
         hipDeviceProp_t prop;
@@ -606,6 +621,7 @@ static int engine_init(qk_engine *e)
     HIPCHECK(hipStreamCreateWithFlags(&e->agc_stream, hipStreamNonBlocking));
     HIPCHECK(hipStreamCreateWithFlags(&e->fe_stream, hipStreamNonBlocking));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_fe, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_fe2, hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_read[0], hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_read[1], hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_chain, hipEventDisableTiming));
@@ -1065,23 +1081,34 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             if (n_in > 0) {
                 IirArgs a{in.view(), out.view(), n_in, st.iir_kind, st.a0, st.a1, st.b1, st.iir_state, d_list, nlist};
                 Timer tm(e, st.timer);
-                hipLaunchKernelGGL(k_serial_iir, dim3((nlist + 63) / 64), dim3(64), 0, e->stream, a);
+                hipLaunchKernelGGL(k_serial_iir, dim3((nlist + IIR_G - 1) / IIR_G), dim3(IIR_T), 0, e->stream, a);
             }
             break;
         }
         case ST_FRAC: {
-            // the reference's position recurrence (quisk.c:581-609), run for this block's n_in inputs
+            // The reference's position recurrence (quisk.c:581-609) does not depend on the data: the host runs it
+            // (the same additions in the same order) and hands the kernel, per output, the index of the newest
+            // input sample and the interpolation position.
             const double fdecim = e->decim_srate / 48000.0;
             const double step = fdecim - 1;
+            Chain::FracSlot &fs = c.frac_slot[c.frac_next];
+            c.frac_next = (c.frac_next + 1) & 3;
+            if (fs.used) HIPCHECK(hipEventSynchronize(fs.ev));       // four blocks back: only a host far ahead of the GPU waits here
             int n_out = 0;
             for (int i = 0; i < n_in; i++) {
-                if (c.frac_dindex < 2) { n_out++; c.frac_dindex += step; }
-                else c.frac_dindex -= 1;
+                if (c.frac_dindex < 2) {
+                    if (n_out >= c.frac_cap) return fail(QK_ERANGE, "internal: fractional decimator output exceeds its buffer");
+                    fs.idx[n_out] = i; fs.pos[n_out] = c.frac_dindex; n_out++;
+                    c.frac_dindex += step;
+                } else c.frac_dindex -= 1;
             }
             out.n = n_out;
-            if (n_out > c.frac_cap) return fail(QK_ERANGE, "internal: fractional decimator output exceeds its buffer");
-            if (n_in > 0)
-                hipLaunchKernelGGL(k_frac_positions, dim3(1), dim3(64), 0, e->stream, c.d_frac_state, step, n_in, c.d_frac_idx, c.d_frac_pos);
+            if (n_out > 0) {
+                hipLaunchKernelGGL(k_stage_frac, dim3((n_out + 255) / 256), dim3(256), 0, e->stream, fs.idx, fs.pos,
+                                   c.d_frac_idx, c.d_frac_pos, n_out);
+                HIPCHECK(hipEventRecord(fs.ev, e->stream));
+                fs.used = true;
+            }
             if (n_out > 0) {
                 FracArgs a{in.view(), out.view(), c.d_frac_idx, c.d_frac_pos, n_out, d_list};
                 Timer tm(e, st.timer);
@@ -1111,7 +1138,11 @@ static void launch_frontend(qk_engine *e, const FrontArgs &fa, int nspans)
         const size_t lds = FeLayout<FE_CHUNK>::total(S) * sizeof(double);
         hipLaunchKernelGGL((k_frontend<S, FE_CHUNK>), dim3(nspans, e->nrx), dim3(FE_THREADS), lds, e->fe_stream, fa);
     } else {
-        hipLaunchKernelGGL((k_frontend_wave<S>), dim3(nspans, e->nrx), dim3(64), 0, e->fe_stream, fa);
+        // a fixed number of workgroups per receiver walks the spans: with fe_share < 100 the front end leaves part of
+        // every CU's LDS and registers to the kernels of the other two streams
+        int gx = nspans;
+        if (e->fe_share < 100) gx = std::max(1, std::min(nspans, (int)((long long)e->fe_slots * e->fe_share / 100 / std::max(1, e->nrx))));
+        hipLaunchKernelGGL((k_frontend_wave<S>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
     }
 }
 
@@ -1157,13 +1188,13 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             // spans: enough workgroups to fill 256 CUs several times over, but long enough that the warm-up
             // (44 * 2^S samples per span) stays a small fraction
             const long long unit = e->fe_variant ? FW_CHUNK : FE_CHUNK;
-            const long long target_wgs = e->fe_variant ? 2LL * e->fe_slots : 2048;
+            const long long target_wgs = e->fe_variant ? (long long)e->fe_rounds * e->fe_slots : 2048;
             long long want = std::max(1LL, target_wgs / std::max(1, e->nrx));
             long long span = (consumed + want - 1) / want;
             span = std::max(span, 4 * unit);
             span = (span + unit - 1) / unit * unit;
             const int nspans = (int)((consumed + span - 1) / span);
-            fa.span_len = (int)span;
+            fa.span_len = (int)span; fa.nspans = nspans;
             switch (S) {
             case 1: launch_frontend<1>(e, fa, nspans); break;
             case 2: launch_frontend<2>(e, fa, nspans); break;
@@ -1190,8 +1221,11 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             hipLaunchKernelGGL(k_save_tails, dim3(1, 2, e->nrx), dim3(256), 0, e->fe_stream, th);
         F.front_last_n = f0.n;
     }
-    HIPCHECK(hipEventRecord(e->ev_fe, e->fe_stream));
-    HIPCHECK(hipStreamWaitEvent(e->stream, e->ev_fe, 0));
+    {
+        hipEvent_t evf = (e->stats.blocks & 1) ? e->ev_fe2 : e->ev_fe;
+        HIPCHECK(hipEventRecord(evf, e->fe_stream));
+        HIPCHECK(hipStreamWaitEvent(e->stream, evf, 0));
+    }
     // ---- remaining integer decimation, all receivers ----
     int rc = run_chain(e, F, F.streams[0], nullptr, e->nrx);
     if (rc != QK_OK) return rc;
@@ -1333,6 +1367,7 @@ void qk_destroy(qk_engine *e)
     if (e->ev_chain) hipEventDestroy(e->ev_chain);
     for (auto &ev : e->ev_agc) if (ev) hipEventDestroy(ev);
     if (e->ev_fe) hipEventDestroy(e->ev_fe);
+    if (e->ev_fe2) hipEventDestroy(e->ev_fe2);
     for (auto &ev : e->ev_read) if (ev) hipEventDestroy(ev);
     if (e->fe_stream) hipStreamDestroy(e->fe_stream);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -1646,7 +1681,8 @@ int qk_set_timing(qk_engine *e, int on)
 {
     ENGINE_ENTER(e);
     int rc = drain_events(e);
-    e->timing = on == 1 ? 0x1ffu : (unsigned)on >> 1;     // 1 = everything; otherwise bit (b + 1) selects group b
+    e->timing = on == 1 ? 0x1ffu : (unsigned)on >> 1;
+     // 1 = everything; otherwise bit (b + 1) selects group b
     return rc;
 }
 

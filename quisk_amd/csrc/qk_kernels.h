@@ -78,7 +78,8 @@ struct FrontArgs {
     StreamView out;            // stage-S output stream (2 planes)
     long long J0;              // global index of the first stage-S output of this block
     long long g_lo0, g_end;    // global input range [g_lo0, g_end) consumed by this block's outputs (multiples of 2^S)
-    int span_len;              // input samples per workgroup (multiple of 2^S)
+    int span_len;              // input samples per span (multiple of 2^S)
+    int nspans;                // spans per receiver; a workgroup walks spans blockIdx.x, blockIdx.x + gridDim.x, ...
 };
 
 // Mixer alone (no half-band in front of the FIR chain: rates < 96 ksps).
@@ -394,15 +395,17 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
 {
     __shared__ __attribute__((aligned(16))) double smem[FwLayout::total(S)];
     const int rx = blockIdx.y, lane = threadIdx.x;
-    const long long g_lo = a.g_lo0 + (long long)blockIdx.x * a.span_len;
-    if (g_lo >= a.g_end) return;
-    const long long g_hi = (g_lo + a.span_len < a.g_end) ? g_lo + a.span_len : a.g_end;
     constexpr int W = FwLayout::warm(S);
     constexpr int NIT = FW_CHUNK / 64;
-    for (int i = lane; i < FwLayout::level_off(S); i += 64) smem[i] = 0.0;
     const int mix = a.mt.mix_on[rx];
     const double2 *histp = a.hist + (long long)rx * a.H;
     double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
+  for (int span = blockIdx.x; span < a.nspans; span += gridDim.x) {
+    const long long g_lo = a.g_lo0 + (long long)span * a.span_len;
+    if (g_lo >= a.g_end) break;
+    const long long g_hi = (g_lo + a.span_len < a.g_end) ? g_lo + a.span_len : a.g_end;
+    __syncthreads();
+    for (int i = lane; i < FwLayout::level_off(S); i += 64) smem[i] = 0.0;
     long long pos = g_lo - W;
     double *E0 = fw_arr(smem, 0, 0, 0), *O0 = fw_arr(smem, 0, 0, 1);
     double *E1 = fw_arr(smem, 0, 1, 0), *O1 = fw_arr(smem, 0, 1, 1);
@@ -495,6 +498,7 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
         __syncthreads();
         pos = npos; c = nc;
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -626,18 +630,13 @@ __global__ __launch_bounds__(256) void k_hb_interp(HbInterpArgs a)
 // Fractional decimator (cFracDecim, quisk.c:570-613): 4-point Lagrange interpolation at position dindex
 // between the last four samples.  The position recurrence does not depend on the data, so the host runs it
 // (same operations, same order) and hands over, per output, the index of the newest sample and dindex.
-// The position recurrence itself, on one lane (the host runs the same recurrence to learn the output count).
-__global__ void k_frac_positions(double *dindex_state, double step, int n_in, int *idx, double *pos)
+// The positions come from pinned host memory that the device can read: a tiny kernel moves them, because an
+// asynchronous host-to-device copy in the per-block path slows down every later launch on the host side
+// (measured: ~65 us per call until the copy has run).
+__global__ __launch_bounds__(256) void k_stage_frac(const int *h_idx, const double *h_pos, int *d_idx, double *d_pos, int n)
 {
-#pragma clang fp contract(off)
-    if (threadIdx.x || blockIdx.x) return;
-    double d = *dindex_state;
-    int m = 0;
-    for (int i = 0; i < n_in; i++) {
-        if (d < 2) { idx[m] = i; pos[m] = d; m++; d += step; }
-        else d -= 1;
-    }
-    *dindex_state = d;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { d_idx[i] = h_idx[i]; d_pos[i] = h_pos[i]; }
 }
 struct FracArgs { StreamView in, out; const int *idx; const double *pos; int n_out; const int *rx_list; };
 __global__ __launch_bounds__(256) void k_fracdecim(FracArgs a)
@@ -725,34 +724,72 @@ __global__ __launch_bounds__(256) void k_fm_disc(FmDiscArgs a)
     sv_ptr(a.out, rx, 0)[i] = a.fs * atan2(im, re);
 }
 
-// Serial one-pole recurrences, one lane per receiver.
+// Serial one-pole recurrences.
 //   kind 0: AM DC removal (quisk.c:1869-1871): d = m + 0.99 dc; y = d - dc; dc = d.
 //   kind 1: FM de-emphasis (quisk.c:1898-1900): y = x a0 + x1 a1 - y1 b1.
+// A workgroup owns IIR_G receivers.  All its lanes move tiles of IIR_T samples per receiver between HBM and LDS
+// with coalesced accesses (the next tile's loads are issued before the serial walk starts); lanes 0..IIR_G-1
+// then walk one receiver each through the tile in LDS (row pitch IIR_T + 1 doubles: the IIR_G rows start on
+// different banks).  The recurrences keep the reference's separately rounded products and sums.
+#define IIR_G 16
+#define IIR_T 256
 struct IirArgs { StreamView in, out; int n, kind; double a0, a1, b1; double *state; const int *rx_list; int n_rx; };
-__global__ __launch_bounds__(64) void k_serial_iir(IirArgs a)
+__global__ __launch_bounds__(IIR_T) void k_serial_iir(IirArgs a)
 {
-#pragma clang fp contract(off)      // recurrences: keep the reference's separately rounded products and sums
-    const int li = blockIdx.x * 64 + threadIdx.x;
-    if (li >= a.n_rx) return;
-    const int rx = a.rx_list ? a.rx_list[li] : li;
-    const double *__restrict__ p = sv_ptr(a.in, rx, 0);
-    double *__restrict__ o = sv_ptr(a.out, rx, 0);
-    double s0 = a.state[2 * rx], s1 = a.state[2 * rx + 1];
-    if (a.kind == 0) {
-        for (int i = 0; i < a.n; i++) {
-            const double d = p[i] + s0 * 0.99;
-            o[i] = d - s0;
-            s0 = d;
-        }
-    } else {
-        for (int i = 0; i < a.n; i++) {     // s0 = x1, s1 = y1
-            const double x = p[i];
-            const double y = x * a.a0 + s0 * a.a1 - s1 * a.b1;
-            o[i] = y;
-            s0 = x; s1 = y;
-        }
+#pragma clang fp contract(off)
+    __shared__ double tile[IIR_G][IIR_T + 1];
+    const int t = threadIdx.x;
+    const int g0 = blockIdx.x * IIR_G;
+    const int ng = (a.n_rx - g0 < IIR_G) ? a.n_rx - g0 : IIR_G;
+    const double *p[IIR_G]; double *o[IIR_G];
+#pragma unroll
+    for (int r = 0; r < IIR_G; r++) {
+        const int li = g0 + (r < ng ? r : 0);
+        const int rx = a.rx_list ? a.rx_list[li] : li;
+        p[r] = sv_ptr(a.in, rx, 0); o[r] = sv_ptr(a.out, rx, 0);
     }
-    a.state[2 * rx] = s0; a.state[2 * rx + 1] = s1;
+    int my_rx = 0;
+    double s0 = 0.0, s1 = 0.0;
+    if (t < ng) {
+        my_rx = a.rx_list ? a.rx_list[g0 + t] : g0 + t;
+        s0 = a.state[2 * my_rx]; s1 = a.state[2 * my_rx + 1];
+    }
+    double v[IIR_G];
+#pragma unroll
+    for (int r = 0; r < IIR_G; r++) v[r] = (r < ng && t < a.n) ? p[r][t] : 0.0;
+    for (int t0 = 0; t0 < a.n; t0 += IIR_T) {
+#pragma unroll
+        for (int r = 0; r < IIR_G; r++) tile[r][t] = v[r];
+        __syncthreads();
+        const int nt = t0 + IIR_T + t;
+#pragma unroll
+        for (int r = 0; r < IIR_G; r++) v[r] = (r < ng && nt < a.n) ? p[r][nt] : 0.0;
+        if (t < ng) {
+            const int cnt = (a.n - t0 < IIR_T) ? a.n - t0 : IIR_T;
+            double *row = tile[t];
+            if (a.kind == 0) {
+                for (int i = 0; i < cnt; i++) {
+                    const double d = row[i] + s0 * 0.99;
+                    row[i] = d - s0;
+                    s0 = d;
+                }
+            } else {
+                for (int i = 0; i < cnt; i++) {     // s0 = x1, s1 = y1
+                    const double x = row[i];
+                    const double y = x * a.a0 + s0 * a.a1 - s1 * a.b1;
+                    row[i] = y;
+                    s0 = x; s1 = y;
+                }
+            }
+        }
+        __syncthreads();
+        if (t0 + t < a.n) {
+#pragma unroll
+            for (int r = 0; r < IIR_G; r++) if (r < ng) o[r][t0 + t] = tile[r][t];
+        }
+        __syncthreads();
+    }
+    if (t < ng) { a.state[2 * my_rx] = s0; a.state[2 * my_rx + 1] = s1; }
 }
 
 // ------------------------------------------------------------------------------------------------
