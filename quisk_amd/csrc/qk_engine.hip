@@ -37,7 +37,7 @@ constexpr int DEFAULT_TAP_CAP = 1024;
 constexpr int EV_POOL = 2048;
 
 enum StageKind { ST_FIR, ST_INTERP, ST_HBINT, ST_RESAMP, ST_RXF, ST_FMDISC, ST_IIR, ST_FRAC };
-enum ChainClass { CL_SSB = 0, CL_CW, CL_AM, CL_FM, CL_COUNT };
+enum ChainClass { CL_SSB = 0, CL_CW, CL_AM, CL_FM, CL_DGTW, CL_COUNT };    // CL_DGTW: DGT-U/L filtered at the decimated rate
 
 struct Stream {
     double *d = nullptr;
@@ -225,10 +225,13 @@ int filter_rate(int rate, int mode, int bw)
     }
 }
 
-int class_of_mode(int mode)
+int class_of_mode(int mode, int bandwidth)
 {
     switch (mode) {
     case QK_CWL: case QK_CWU: return CL_CW;
+    // DGT-U/L (quisk.c:1922-1973): below DGT_NARROW_FREQ (quisk.c:35) the chain is CW's (two half-bands, FIR98/2, band-pass,
+    // x2, two half-band interpolators; the sideband sign comes from the mode); otherwise the band-pass runs at the decimated rate
+    case QK_DGT_U: case QK_DGT_L: return bandwidth < 3000 ? CL_CW : CL_DGTW;
     case QK_AM: return CL_AM;
     case QK_FM: case QK_DGT_FM: return CL_FM;
     case QK_LSB: case QK_USB: case QK_IMD: return CL_SSB;
@@ -413,6 +416,9 @@ static int build_class(qk_engine *e, int cl)
         rc = iir(0);
         b.fir(e->f_a24p6, 1, T_B);
         b.hbint(1, T_B);
+        break;
+    case CL_DGTW:   // quisk.c:1929-1939, 1955-1965
+        rxf(0, 1);
         break;
     case CL_FM: {   // quisk.c:1887-1921
         rxf(2, 2);
@@ -1394,7 +1400,7 @@ int qk_set_tune(qk_engine *e, int rx, int tune_hz)
 int qk_set_mode(qk_engine *e, int rx, int mode)
 {
     ENGINE_ENTER(e); RX_CHECK(e, rx);
-    const int cl = class_of_mode(mode);
+    const int cl = class_of_mode(mode, e->bandwidth[rx]);
     if (cl < 0) return fail(QK_EUNSUPPORTED, "mode needs an external codec or is not on the GPU path yet");
     if (e->mode[rx] == mode) return QK_OK;
     SYNC_ALL(e);
@@ -1422,6 +1428,8 @@ int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int
     }
     HIPCHECK(hipMemcpy(e->d_ntaps + rx, &n, sizeof(int), hipMemcpyHostToDevice));
     e->ntaps[rx] = n; e->bandwidth[rx] = bandwidth; e->start_offset[rx] = start_offset;
+    const int cl = class_of_mode(e->mode[rx], bandwidth);      // DGT-U/L change chain with the bandwidth
+    if (cl >= 0 && cl != e->cls[rx]) { e->cls[rx] = cl; return upload_members(e); }
     return QK_OK;
 }
 

@@ -12,10 +12,10 @@ from quisk_amd.synth import make_iq, tune_offsets, mode_mix
 pytestmark = pytest.mark.gpu
 
 
-def _stream(fs, modes, tunes, sizes, seed, playback=48000, max_block=None, pre_tol=None):
+def _stream(fs, modes, tunes, sizes, seed, playback=48000, max_block=None, pre_tol=None, bws=None):
     x = make_iq(sum(sizes), fs, tunes, modes, seed)
     eng = Engine(fs, n_receivers=len(modes), playback_rate=playback, max_block=max_block or max(sizes))
-    pr = PairRunner(eng, modes, tunes, pre_tol=pre_tol)
+    pr = PairRunner(eng, modes, tunes, pre_tol=pre_tol, bws=bws)
     pos = 0
     for s in sizes:
         pr.step(x[pos:pos + s])
@@ -71,6 +71,35 @@ def test_modes_192k(mode):
     pr = _stream(192000, [mode], [25000], [9600] * 15, 77 + mode)
     assert pr.samples == 15 * 2400
     pr.check()
+
+
+@pytest.mark.parametrize("mode,bw", [(7, 500), (8, 2400), (7, 3200), (8, 6000), (13, 16000)])
+def test_digital_modes(mode, bw):
+    """DGT-U / DGT-L below and above DGT_NARROW_FREQ (6 ksps and 48 ksps band-pass, quisk.c:1922-1973) and DGT-FM."""
+    pr = _stream(192000, [mode], [-18000], [9600, 4801, 9599, 9600, 9600], 31 + mode, bws=[bw])
+    pr.check()
+
+
+def test_dgt_bandwidth_change_moves_the_receiver_between_chains():
+    """set_filters with a bandwidth across DGT_NARROW_FREQ switches a DGT-U receiver between the two chains; a USB
+    receiver beside it is not disturbed."""
+    fs = 192000
+    eng = Engine(fs, n_receivers=2, max_block=9600)
+    pr = PairRunner(eng, [7, 3], [12000, -30000], bws=[3200, 2800])
+    x = make_iq(9600 * 8, fs, [12000, -30000], [3, 3], 9)
+    for i in range(4):
+        pr.step(x[i * 9600:(i + 1) * 9600])
+    pr.close()
+    pr.check()
+    # an engine first set up wide, then narrowed before the first block: the receiver moves to the 6 ksps chain
+    from _rxsetup import configure_engine
+    eng2 = Engine(fs, n_receivers=1, max_block=9600)
+    configure_engine(eng2, [7], [12000], bws=[3200])
+    pr2 = PairRunner(eng2, [7], [12000], bws=[500])
+    for i in range(4):
+        pr2.step(x[i * 9600:(i + 1) * 9600])
+    pr2.close()
+    pr2.check()
 
 
 @pytest.mark.parametrize("playback", [96000, 192000])
