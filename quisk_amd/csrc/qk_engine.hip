@@ -131,7 +131,7 @@ struct qk_engine {
     Chain front;
     Chain cls_chain[CL_COUNT];
     // per receiver
-    double *d_taps = nullptr; int *d_ntaps = nullptr, *d_mode = nullptr; double *d_release_gain = nullptr;
+    double *d_taps = nullptr; int *d_ntaps = nullptr, *d_mode = nullptr, *d_cls = nullptr; double *d_release_gain = nullptr;
     std::vector<int> ntaps, bandwidth, start_offset;
     AgcState *d_agc = nullptr; double *d_gains = nullptr; int gain_stride = 0;
     int *d_agc_started = nullptr; std::vector<char> agc_started;    // per receiver: has process_agc run once?
@@ -481,6 +481,7 @@ static int build_class(qk_engine *e, int cl)
 
 static int upload_members(qk_engine *e)
 {
+    HIPCHECK(hipMemcpyAsync(e->d_cls, e->cls.data(), sizeof(int) * e->nrx, hipMemcpyHostToDevice, e->stream));
     for (int cl = 0; cl < CL_COUNT; cl++) e->cls_chain[cl].members.clear();
     for (int r = 0; r < e->nrx; r++) e->cls_chain[e->cls[r]].members.push_back(r);
     for (int cl = 0; cl < CL_COUNT; cl++) {
@@ -580,6 +581,7 @@ static int init_receivers(qk_engine *e)
     HIPCHECK(hipMemset(e->d_taps, 0, nrx * 2 * e->tap_cap * sizeof(double)));
     HIPCHECK(hipMalloc(&e->d_ntaps, nrx * sizeof(int)));
     HIPCHECK(hipMemset(e->d_ntaps, 0, nrx * sizeof(int)));
+    HIPCHECK(hipMalloc(&e->d_cls, nrx * sizeof(int)));
     HIPCHECK(hipMalloc(&e->d_mode, nrx * sizeof(int)));
     HIPCHECK(hipMemcpy(e->d_mode, e->mode.data(), nrx * sizeof(int), hipMemcpyHostToDevice));
     std::vector<double> rel(nrx, 80.0);                          // agcReleaseGain, quisk.c:145
@@ -1261,26 +1263,36 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         e->read_pending[q] = true;
         e->fe_blocks++;
     }
-    for (int cl = 0; cl < CL_COUNT; cl++) {
-        Chain &c = e->cls_chain[cl];
-        const int nl = (int)c.members.size(), m = c.n_out;
-        if (!nl || m <= 0) continue;
-        const Stream &play = c.streams[c.play];
+    {
+        static_assert(CL_COUNT <= QK_AGC_CLASSES, "AgcArgs holds one stream view per chain class");
         const int rate = e->cfg.playback_rate;
         AgcArgs a{};
-        a.in = play.view(); a.gains = e->d_gains; a.gain_stride = e->gain_stride; a.n = m;
-        a.buf_size = rate * 15 / 1000; a.n_rx = nl;
-        a.ceiling = 0.7 * QK_CLIP32;                                         // Agc1 max_out, quisk.c:2181
-        a.time_release = 1.0 - exp(-1.0 / rate / e->agc_release_time);       // quisk.c:2045
-        a.release_gain = e->d_release_gain; a.mode = e->d_mode; a.state = e->d_agc;
-        a.out = e->d_out; a.out_stride = (long long)e->out_stride; a.rx_list = c.d_members;
-        a.started = e->d_agc_started;
-        Timer tm(e, QK_KT_AGC, e->agc_stream);
-        hipLaunchKernelGGL(k_agc_gain, dim3(nl), dim3(64), 0, e->agc_stream, a);
-        hipLaunchKernelGGL(k_agc_apply, grid1(m, 1, nl), dim3(256), 0, e->agc_stream, a);
-        for (int r : c.members)
-            if (!e->agc_started[r])
-                hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_agc_started + r), 1, 1, e->agc_stream);
+        int m_max = 0;
+        for (int cl = 0; cl < CL_COUNT; cl++) {
+            Chain &c = e->cls_chain[cl];
+            const bool on = !c.members.empty() && c.n_out > 0;
+            if (c.built) a.in_c[cl] = c.streams[c.play].view();
+            a.n_c[cl] = on ? c.n_out : 0;
+            m_max = std::max(m_max, a.n_c[cl]);
+        }
+        if (m_max > 0) {
+            a.cls = e->d_cls; a.gains = e->d_gains; a.gain_stride = e->gain_stride;
+            a.buf_size = rate * 15 / 1000; a.n_rx = e->nrx;
+            a.ceiling = 0.7 * QK_CLIP32;                                         // Agc1 max_out, quisk.c:2181
+            a.time_release = 1.0 - exp(-1.0 / rate / e->agc_release_time);       // quisk.c:2045
+            a.release_gain = e->d_release_gain; a.mode = e->d_mode; a.state = e->d_agc;
+            a.out = e->d_out; a.out_stride = (long long)e->out_stride;
+            a.started = e->d_agc_started;
+            Timer tm(e, QK_KT_AGC, e->agc_stream);
+            hipLaunchKernelGGL(k_agc_gain, dim3(e->nrx), dim3(64), 0, e->agc_stream, a);
+            hipLaunchKernelGGL(k_agc_apply, grid1(m_max, 1, e->nrx), dim3(256), 0, e->agc_stream, a);
+            for (int cl = 0; cl < CL_COUNT; cl++) {
+                if (a.n_c[cl] <= 0) continue;
+                for (int r : e->cls_chain[cl].members)
+                    if (!e->agc_started[r])
+                        hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_agc_started + r), 1, 1, e->agc_stream);
+            }
+        }
     }
     HIPCHECK(hipEventRecord(e->ev_agc[par], e->agc_stream));
     // ---- carry stream tails ----
@@ -1363,7 +1375,7 @@ void qk_destroy(qk_engine *e)
                     (void *)e->d_bs_out, (void *)e->d_bs_X, (void *)e->d_bs_max})
         if (p) hipFree(p);
     for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
-    void *ptrs[] = {e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps,
+    void *ptrs[] = {e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps, e->d_cls,
                     e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_out,
                     e->d_fft_stage, e->d_fft_Y, e->d_tw4096, e->d_tw_lo, e->d_tw_hi, e->d_window, e->d_fft_avg, e->d_band,
                     e->d_meter, e->d_graph, e->d_pix, e->d_k0};

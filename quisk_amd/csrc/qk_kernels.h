@@ -802,17 +802,21 @@ struct AgcState {
     double themax, gain, delta, target_gain;
     int index_read, index_start, is_clipping, pad;
 };
+#define QK_AGC_CLASSES 8
 struct AgcArgs {
-    StreamView in;             // mono audio at the play rate, hist >= buf_size
+    // one launch serves every receiver: the receivers of chain class c read the play stream in_c[c] (mono audio at the
+    // play rate, hist >= buf_size), n_c[c] new samples this block (0: nothing to do)
+    StreamView in_c[QK_AGC_CLASSES];
+    int n_c[QK_AGC_CLASSES];
+    const int *cls;            // [rx] chain class
     double *gains;             // [rx][cap]
-    int gain_stride, n, buf_size, n_rx;
+    int gain_stride, buf_size, n_rx;
     double ceiling;            // max_out * CLIP32
     double time_release;
     const double *release_gain;   // [rx] agcReleaseGain
     const int *mode;           // [rx]
     AgcState *state;           // [rx]
     double2 *out; long long out_stride;   // [rx][out_stride] interleaved stereo
-    const int *rx_list;
     const int *started;        // [rx] 0 until the receiver's first call: the reference then only initialises
                                // and returns the block untouched (quisk.c:2033-2050)
 };
@@ -935,11 +939,13 @@ __device__ __forceinline__ double agc_chain(double g0, double keep, double add, 
 __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
 {
 #pragma clang fp contract(off)
-    const int rx = a.rx_list ? a.rx_list[blockIdx.x] : blockIdx.x;
-    if (!a.started[rx]) return;
+    const int rx = blockIdx.x;
+    const int cl = a.cls[rx];
+    const int n_new = a.n_c[cl];
+    if (!a.started[rx] || n_new <= 0) return;
     __builtin_amdgcn_s_setprio(3);      // a latency-bound wave among the front end's throughput-bound ones: issue first
     const int lane = threadIdx.x;
-    const double *__restrict__ p = sv_ptr(a.in, rx, 0);
+    const double *__restrict__ p = sv_ptr(a.in_c[cl], rx, 0);
     double *__restrict__ g = a.gains + (long long)rx * a.gain_stride;
     AgcState s = a.state[rx];
     AgcConst c;
@@ -952,7 +958,7 @@ __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
     // that the compiler can count them in flight instead of draining the queue; lanes past the end are never
     // `mine`.  The tile loop is unrolled by hand by the depth of the rotation (three registers), so that no
     // register copy has to wait for a load that was only just issued.
-    const int last = a.n - 1;
+    const int last = n_new - 1;
 #ifdef AGC_PROF
     long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = clock64(), t_begin = t_last;
 #define AGC_PROBE(k) do { const long long t_ = clock64(); tp[k] += t_ - t_last; t_last = clock64(); tp[7] += t_last - t_; } while (0)
@@ -961,7 +967,7 @@ __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
 #endif
     auto tile = [&](const int i0, const double mv) {
         AGC_PROBE(0);                                                   // tile loop: load issue, wait, magnitude
-        const int cnt = (a.n - i0 < 64) ? a.n - i0 : 64;
+        const int cnt = (n_new - i0 < 64) ? n_new - i0 : 64;
         double gv = 0.0;                                               // gain in force at this lane's sample
         int start = 0;
         while (start < cnt) {
@@ -1023,19 +1029,19 @@ __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
     // (the prologue loads are consumed here, so the loop is entered with nothing in flight and its waits count
     // only what the loop itself issued)
     double ra = fabs(p[min(lane, last)]), rb = fabs(p[min(64 + lane, last)]), rc;
-    for (int i0 = 0; i0 < a.n; i0 += 192) {
+    for (int i0 = 0; i0 < n_new; i0 += 192) {
         rc = p[min(i0 + 128 + lane, last)];
         tile(i0, fabs(ra));
-        if (i0 + 64 >= a.n) break;
+        if (i0 + 64 >= n_new) break;
         ra = p[min(i0 + 192 + lane, last)];
         tile(i0 + 64, fabs(rb));
-        if (i0 + 128 >= a.n) break;
+        if (i0 + 128 >= n_new) break;
         rb = p[min(i0 + 256 + lane, last)];
         tile(i0 + 128, fabs(rc));
     }
 #ifdef AGC_PROF
     if (lane == 0 && rx == 0)
-        printf("agc prof: n %d total %lld | loop %lld pre %lld chain %lld event %lld max %lld commit %lld store %lld probe %lld\n", a.n,
+        printf("agc prof: n %d total %lld | loop %lld pre %lld chain %lld event %lld max %lld commit %lld store %lld probe %lld\n", n_new,
                (long long)(clock64() - t_begin), tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7]);
 #endif
     if (lane == 0) a.state[rx] = s;
@@ -1044,9 +1050,10 @@ __global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
 {
 #pragma clang fp contract(off)
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
-    const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
-    const double *p = sv_ptr(a.in, rx, 0) + i;
+    const int rx = blockIdx.z;
+    const int cl = a.cls[rx];
+    if (i >= a.n_c[cl]) return;
+    const double *p = sv_ptr(a.in_c[cl], rx, 0) + i;
     double d;
     if (!a.started[rx]) {
         d = p[0];
