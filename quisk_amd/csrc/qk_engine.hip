@@ -1089,7 +1089,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             if (n_in > 0) {
                 IirArgs a{in.view(), out.view(), n_in, st.iir_kind, st.a0, st.a1, st.b1, st.iir_state, d_list, nlist};
                 Timer tm(e, st.timer);
-                hipLaunchKernelGGL(k_serial_iir, dim3((nlist + IIR_G - 1) / IIR_G), dim3(IIR_T), 0, e->stream, a);
+                hipLaunchKernelGGL(k_serial_iir, dim3(nlist), dim3(64), 0, e->stream, a);
             }
             break;
         }

@@ -31,6 +31,13 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b)
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 // The 12 half-band constants (filter.c:359-362).
 #define HB_C0 0.000018566625444266
 #define HB_C1 -0.000118469698701817
@@ -724,72 +731,95 @@ __global__ __launch_bounds__(256) void k_fm_disc(FmDiscArgs a)
     sv_ptr(a.out, rx, 0)[i] = a.fs * atan2(im, re);
 }
 
-// Serial one-pole recurrences.
+// One-pole recurrences of the demodulators, as a scan.
 //   kind 0: AM DC removal (quisk.c:1869-1871): d = m + 0.99 dc; y = d - dc; dc = d.
 //   kind 1: FM de-emphasis (quisk.c:1898-1900): y = x a0 + x1 a1 - y1 b1.
-// A workgroup owns IIR_G receivers.  All its lanes move tiles of IIR_T samples per receiver between HBM and LDS
-// with coalesced accesses (the next tile's loads are issued before the serial walk starts); lanes 0..IIR_G-1
-// then walk one receiver each through the tile in LDS (row pitch IIR_T + 1 doubles: the IIR_G rows start on
-// different banks).  The recurrences keep the reference's separately rounded products and sums.
-#define IIR_G 16
-#define IIR_T 256
+// Both are s[n] = u[n] + lambda s[n-1] (u = m, lambda = 0.99; u = x a0 + x1 a1, lambda = -b1).  One wave per receiver walks
+// tiles of 64 x IIR_K samples: lane L runs the recurrence over its IIR_K consecutive samples from a zero state, the 64
+// segment ends are chained (S_in(L+1) = end_L + lambda^len_L S_in(L), 64 wave-uniform steps), and every lane adds
+// lambda^(k+1) S_in(L) to its local values.  The values differ from a sample-by-sample walk only by rounding order
+// (|lambda| < 1: errors do not grow), inside the 1e-9 contract; a serial walk of 32768 samples per receiver took 0.65 ms.
+#define IIR_K 16
 struct IirArgs { StreamView in, out; int n, kind; double a0, a1, b1; double *state; const int *rx_list; int n_rx; };
-__global__ __launch_bounds__(IIR_T) void k_serial_iir(IirArgs a)
+__global__ __launch_bounds__(64) void k_serial_iir(IirArgs a)
 {
 #pragma clang fp contract(off)
-    __shared__ double tile[IIR_G][IIR_T + 1];
-    const int t = threadIdx.x;
-    const int g0 = blockIdx.x * IIR_G;
-    const int ng = (a.n_rx - g0 < IIR_G) ? a.n_rx - g0 : IIR_G;
-    const double *p[IIR_G]; double *o[IIR_G];
+    const int lane = threadIdx.x;
+    const int rx = a.rx_list ? a.rx_list[blockIdx.x] : blockIdx.x;
+    const double *__restrict__ p = sv_ptr(a.in, rx, 0);
+    double *__restrict__ o = sv_ptr(a.out, rx, 0);
+    const double lam = a.kind == 0 ? 0.99 : -a.b1;
+    double pw[IIR_K];                                   // lambda^(k+1)
+    pw[0] = lam;
 #pragma unroll
-    for (int r = 0; r < IIR_G; r++) {
-        const int li = g0 + (r < ng ? r : 0);
-        const int rx = a.rx_list ? a.rx_list[li] : li;
-        p[r] = sv_ptr(a.in, rx, 0); o[r] = sv_ptr(a.out, rx, 0);
-    }
-    int my_rx = 0;
-    double s0 = 0.0, s1 = 0.0;
-    if (t < ng) {
-        my_rx = a.rx_list ? a.rx_list[g0 + t] : g0 + t;
-        s0 = a.state[2 * my_rx]; s1 = a.state[2 * my_rx + 1];
-    }
-    double v[IIR_G];
+    for (int k = 1; k < IIR_K; k++) pw[k] = pw[k - 1] * lam;
+    double xprev = a.state[2 * rx];                     // kind 1: x[n-1]; kind 0: unused
+    double S = a.kind == 0 ? a.state[2 * rx] : a.state[2 * rx + 1];     // the recurrence state before the tile
+    for (int t0 = 0; t0 < a.n; t0 += 64 * IIR_K) {
+        const int rem = a.n - t0;
+        const int K = rem >= 64 * IIR_K ? IIR_K : (rem + 63) / 64;       // samples per lane in this tile
+        const int base = t0 + lane * K;
+        int v = a.n - base;                              // valid samples of this lane
+        v = v < 0 ? 0 : (v > K ? K : v);
+        double x[IIR_K];
 #pragma unroll
-    for (int r = 0; r < IIR_G; r++) v[r] = (r < ng && t < a.n) ? p[r][t] : 0.0;
-    for (int t0 = 0; t0 < a.n; t0 += IIR_T) {
+        for (int k = 0; k < IIR_K; k++) x[k] = k < v ? p[base + k] : 0.0;
+        // u[k]
+        double xlast = 0.0;
 #pragma unroll
-        for (int r = 0; r < IIR_G; r++) tile[r][t] = v[r];
-        __syncthreads();
-        const int nt = t0 + IIR_T + t;
+        for (int k = 0; k < IIR_K; k++) if (k < v) xlast = x[k];
+        if (a.kind == 1) {
+            // x[-1] of the lane: the last sample of the nearest lane below that has one, or the carried x1
+            double xm1 = __shfl_up(xlast, 1, 64);
+            if (lane == 0) xm1 = xprev;
+            // (lanes are filled from 0 upwards, so every lane below a non-empty lane is full: its predecessor is lane - 1)
+            double prev = xm1;
 #pragma unroll
-        for (int r = 0; r < IIR_G; r++) v[r] = (r < ng && nt < a.n) ? p[r][nt] : 0.0;
-        if (t < ng) {
-            const int cnt = (a.n - t0 < IIR_T) ? a.n - t0 : IIR_T;
-            double *row = tile[t];
-            if (a.kind == 0) {
-                for (int i = 0; i < cnt; i++) {
-                    const double d = row[i] + s0 * 0.99;
-                    row[i] = d - s0;
-                    s0 = d;
-                }
-            } else {
-                for (int i = 0; i < cnt; i++) {     // s0 = x1, s1 = y1
-                    const double x = row[i];
-                    const double y = x * a.a0 + s0 * a.a1 - s1 * a.b1;
-                    row[i] = y;
-                    s0 = x; s1 = y;
-                }
+            for (int k = 0; k < IIR_K; k++) {
+                const double cur = x[k];
+                x[k] = cur * a.a0 + prev * a.a1;
+                prev = cur;
             }
         }
-        __syncthreads();
-        if (t0 + t < a.n) {
+        // local recurrence from a zero state
+        double l = 0.0, lend = 0.0;
 #pragma unroll
-            for (int r = 0; r < IIR_G; r++) if (r < ng) o[r][t0 + t] = tile[r][t];
+        for (int k = 0; k < IIR_K; k++) {
+            l = x[k] + l * lam;
+            x[k] = l;
+            if (k < v) lend = l;
         }
-        __syncthreads();
+        double fl = 1.0;                                  // lambda^v
+#pragma unroll
+        for (int k = 0; k < IIR_K; k++) if (k < v) fl = pw[k];
+        // chain the segment ends: Sin = state in front of this lane's first sample
+        double Sin = 0.0, run = S;
+        for (int L = 0; L < 64; L++) {
+            if (lane == L) Sin = run;
+            run = readlane_f64(lend, L) + readlane_f64(fl, L) * run;
+        }
+        // fix up and store
+        if (a.kind == 0) {
+            double dprev = Sin;
+#pragma unroll
+            for (int k = 0; k < IIR_K; k++) {
+                const double d = x[k] + pw[k] * Sin;
+                if (k < v) o[base + k] = d - dprev;
+                dprev = d;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < IIR_K; k++) if (k < v) o[base + k] = x[k] + pw[k] * Sin;
+        }
+        S = run;
+        // the last valid sample of the tile sits in the highest non-empty lane
+        const int nv = rem < 64 * K ? rem : 64 * K;
+        xprev = readlane_f64(xlast, (nv - 1) / K);
     }
-    if (t < ng) { a.state[2 * my_rx] = s0; a.state[2 * my_rx + 1] = s1; }
+    if (lane == 0) {
+        if (a.kind == 0) a.state[2 * rx] = S;
+        else { a.state[2 * rx] = xprev; a.state[2 * rx + 1] = S; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -820,12 +850,6 @@ struct AgcArgs {
     const int *started;        // [rx] 0 until the receiver's first call: the reference then only initialises
                                // and returns the block untouched (quisk.c:2033-2050)
 };
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
 
 // One sample of the reference's state machine, verbatim (quisk.c:2076-2131).
 struct AgcConst { double rel, tr, keep, ceil_, bs; int buf_size; bool fm; };
