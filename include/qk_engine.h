@@ -66,6 +66,14 @@ int qk_set_agc(qk_engine *e, int rx, double release_gain);
 /* agc_release_time (quisk.c:146; from the config file, quisk.c:3833).  Must be set before the first block. */
 int qk_set_agc_release_time(qk_engine *e, double seconds);
 
+/* Input conditioning of the full-rate stream, applied in front of the spectrum and the mixer, in the reference's
+ * order.  qk_set_dc_remove: dc_remove_bw of DCremove (sound.c:165-230; set_sparams, sound.c:1253-1262): 0 = off (the
+ * engine's default; Quisk's configuration default is 100), 1 = subtract the average of two-second stretches, > 1 = one-pole
+ * DC blocker of that bandwidth in Hz.  qk_set_invert_spectrum: invert_spectrum (quisk.c:4174-4182, applied at
+ * quisk.c:2315-2320): conjugate every sample.  The noise blanker (quisk.c:615-720) is not built. */
+int qk_set_dc_remove(qk_engine *e, int bandwidth);
+int qk_set_invert_spectrum(qk_engine *e, int on);
+
 /* quisk_process_samples (quisk.h:258, quisk.c:2149-2616), for all receivers at once.
  * iq: n interleaved (re, im) doubles = C99 `complex double`, in HOST memory (copied in) ... */
 int qk_process_samples(qk_engine *e, const double *iq_host, int n);

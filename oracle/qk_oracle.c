@@ -990,3 +990,53 @@ int qko_bscope_release(qko_bscope *b, int clock, double zoom, double deltaf, dou
     for (i = 0; i < L; i++) b->avg[i] = 0;
     return count;
 }
+
+/* ---- input conditioning ---------------------------------------------------------------- */
+void qko_dcremove_init(qko_dcstate *d) { memset(d, 0, sizeof *d); d->alpha = 0.95; }
+void qko_dcremove(qko_dcstate *d, qko_cd *x, int n, int sample_rate, int dc_remove_bw, int key_state)
+{   /* DCremove, sound.c:165-230 (quisk_is_vna == 0) */
+    int i;
+    double omega, Qsin, Qcos, H0, xx;
+    qko_cd c;
+    if (sample_rate != d->old_sample_rate || dc_remove_bw != d->old_bandwidth) {
+        d->old_sample_rate = sample_rate;
+        d->old_bandwidth = dc_remove_bw;
+        if (d->old_bandwidth > 0) {
+            omega = M_PI * d->old_bandwidth / (d->old_sample_rate / 2.0);
+            Qsin = sin(omega);
+            Qcos = cos(omega);
+            H0 = 1.0 / sqrt(2.0);
+            xx = ((Qcos - 1) * (Qcos - 1) + Qsin * Qsin) / (H0 * H0) - Qsin * Qsin;
+            xx = sqrt(xx);
+            d->alpha = Qcos - xx;
+        }
+    }
+    if (d->old_bandwidth == 0) {
+    } else if (d->old_bandwidth == 1) {
+        if (key_state) {
+            d->dc_key_delay = 0; d->dc_sum = 0; d->dc_count = 0;
+        } else if (d->dc_key_delay < d->old_sample_rate) {
+            d->dc_key_delay += n;
+        } else {
+            d->dc_count += n;
+            for (i = 0; i < n; i++) d->dc_sum += x[i];
+            if (d->dc_count > d->old_sample_rate * 2) {
+                d->dc_average = d->dc_sum / d->dc_count;
+                d->dc_sum = 0;
+                d->dc_count = 0;
+            }
+        }
+        for (i = 0; i < n; i++) x[i] -= d->dc_average;
+    } else {
+        for (i = 0; i < n; i++) {
+            c = x[i] + d->dc_remove * d->alpha;
+            x[i] = c - d->dc_remove;
+            d->dc_remove = c;
+        }
+    }
+}
+void qko_invert_spectrum(qko_cd *x, int n)
+{   /* quisk.c:2315-2320 */
+    int i;
+    for (i = 0; i < n; i++) x[i] = conj(x[i]);
+}

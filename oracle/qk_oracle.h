@@ -134,6 +134,15 @@ void qko_bscope_free(qko_bscope *b);
 void qko_bscope_add(qko_bscope *b, const double *samples);
 int  qko_bscope_release(qko_bscope *b, int clock, double zoom, double deltaf, double *out, int graph_width, double *adc_level);
 
+/* input conditioning in front of quisk_process_samples: DCremove (sound.c:165-230, statics as a struct) and the spectrum
+ * inversion of quisk.c:2315-2320 */
+typedef struct {
+    int old_sample_rate, old_bandwidth; double alpha; qko_cd dc_remove, dc_average, dc_sum; int dc_count, dc_key_delay;
+} qko_dcstate;
+void qko_dcremove_init(qko_dcstate *d);
+void qko_dcremove(qko_dcstate *d, qko_cd *x, int n, int sample_rate, int dc_remove_bw, int key_state);
+void qko_invert_spectrum(qko_cd *x, int n);
+
 /* ---- batch driver used as the timed CPU baseline --------------------------------- */
 /* run nrx receivers (already configured) over the same input block; audio of receiver r is written to
  * out + r*out_stride; counts[r] receives the sample count.  Receivers are processed one after the other. */

@@ -136,6 +136,12 @@ struct qk_engine {
     AgcState *d_agc = nullptr; double *d_gains = nullptr; int gain_stride = 0;
     int *d_agc_started = nullptr; std::vector<char> agc_started;    // per receiver: has process_agc run once?
     double agc_release_time = 1.0;
+    // input conditioning (DCremove, sound.c:165-230; spectrum inversion, quisk.c:2315-2320)
+    int dc_bw = 0, invert = 0;
+    double dc_alpha = 0.95; int dc_alpha_bw = -1;
+    long long dc_key_delay = 0, dc_count = 0;
+    double2 *d_cond = nullptr, *d_dc_seg_end = nullptr, *d_dc_seg_in = nullptr, *d_dc_state = nullptr;   // d_dc_state: [0] recurrence, [1] sum, [2] average
+    double2 *d_dc_partial = nullptr;
     // output
     double2 *d_out = nullptr; size_t out_stride = 0;
     std::vector<int> out_count;
@@ -666,6 +672,15 @@ static int engine_init(qk_engine *e)
         HIPCHECK(hipMemcpy(e->d_tw4096, tw.data(), sizeof(double2) * 4096, hipMemcpyHostToDevice));
     }
     HIPCHECK(hipMalloc(&e->d_in, (size_t)cfg.max_block * sizeof(double2)));
+    {
+        const int nseg = (cfg.max_block + DC_SEG - 1) / DC_SEG;
+        HIPCHECK(hipMalloc(&e->d_cond, (size_t)cfg.max_block * sizeof(double2)));
+        HIPCHECK(hipMalloc(&e->d_dc_seg_end, (size_t)nseg * sizeof(double2)));
+        HIPCHECK(hipMalloc(&e->d_dc_seg_in, (size_t)nseg * sizeof(double2)));
+        HIPCHECK(hipMalloc(&e->d_dc_state, 3 * sizeof(double2)));
+        HIPCHECK(hipMemset(e->d_dc_state, 0, 3 * sizeof(double2)));
+        HIPCHECK(hipMalloc(&e->d_dc_partial, 256 * sizeof(double2)));
+    }
     if (e->nrx > 0) { rc = init_receivers(e); if (rc != QK_OK) return rc; }
     if (cfg.fft_size > 0) { rc = init_spectrum(e); if (rc != QK_OK) return rc; }
     e->ev_pool.resize(EV_POOL);
@@ -1154,11 +1169,53 @@ static void launch_frontend(qk_engine *e, const FrontArgs &fa, int nspans)
     }
 }
 
+// DCremove and spectrum inversion in front of everything else; returns the buffer the rest of the block reads
+static const double2 *condition_input(qk_engine *e, const double2 *x, int n)
+{
+    if (e->dc_bw <= 0 && !e->invert) return x;
+    hipStream_t st = e->fe_stream;
+    const int fs = e->cfg.sample_rate;
+    if (e->dc_bw > 1) {
+        if (e->dc_alpha_bw != e->dc_bw) {                 // sound.c:179-191
+            const double omega = M_PI * e->dc_bw / (fs / 2.0);
+            const double Qsin = sin(omega), Qcos = cos(omega), H0 = 1.0 / sqrt(2.0);
+            double xx = ((Qcos - 1) * (Qcos - 1) + Qsin * Qsin) / (H0 * H0) - Qsin * Qsin;
+            xx = sqrt(xx);
+            e->dc_alpha = Qcos - xx;
+            e->dc_alpha_bw = e->dc_bw;
+        }
+        const int nseg = (n + DC_SEG - 1) / DC_SEG;
+        DcArgs a{x, e->d_cond, n, e->dc_alpha, pow(e->dc_alpha, (double)DC_SEG), e->d_dc_seg_end, e->d_dc_seg_in, e->invert};
+        hipLaunchKernelGGL(k_dc_iir<0>, dim3(nseg), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_dc_chain, dim3(1), dim3(64), 0, st, e->d_dc_seg_end, e->d_dc_seg_in, nseg, a.alpha_seg,
+                           pow(e->dc_alpha, (double)(n - (nseg - 1) * DC_SEG)), e->d_dc_state);
+        hipLaunchKernelGGL(k_dc_iir<1>, dim3(nseg), dim3(64), 0, st, a);
+        return e->d_cond;
+    }
+    if (e->dc_bw == 1) {                                  // sound.c:198-222 with key_state == 0 (receive)
+        if (e->dc_key_delay < fs) {
+            e->dc_key_delay += n;
+        } else {
+            e->dc_count += n;
+            const int close_stretch = e->dc_count > 2LL * fs;
+            hipLaunchKernelGGL(k_dc_partial, dim3(256), dim3(256), 0, st, x, n, e->d_dc_partial);
+            hipLaunchKernelGGL(k_dc_final, dim3(1), dim3(64), 0, st, e->d_dc_partial, 256, e->d_dc_state + 1, e->d_dc_state + 2,
+                               close_stretch, (double)e->dc_count);
+            if (close_stretch) e->dc_count = 0;
+        }
+        hipLaunchKernelGGL(k_dc_sub, dim3((n + 255) / 256), dim3(256), 0, st, x, e->d_cond, n, e->d_dc_state + 2, e->invert);
+        return e->d_cond;
+    }
+    hipLaunchKernelGGL(k_dc_sub, dim3((n + 255) / 256), dim3(256), 0, st, x, e->d_cond, n, (const double2 *)nullptr, 1);
+    return e->d_cond;
+}
+
 static int process_device(qk_engine *e, const double2 *x, int n)
 {
     if (n < 0 || n > e->cfg.max_block) return fail(QK_ERANGE, "block larger than max_block");
     if (n == 0) { for (auto &c : e->out_count) c = 0; return QK_OK; }
     Timer block_timer(e, 8);
+    x = condition_input(e, x, n);
     // ---- display spectrum: frames of the samples as they arrive, before the mixer (quisk.c:2324-2348) ----
     if (e->fftN > 0) { int rcs = feed_spectrum(e, x, n); if (rcs != QK_OK) return rcs; }
     if (e->nrx == 0) {
@@ -1375,7 +1432,7 @@ void qk_destroy(qk_engine *e)
                     (void *)e->d_bs_out, (void *)e->d_bs_X, (void *)e->d_bs_max})
         if (p) hipFree(p);
     for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
-    void *ptrs[] = {e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps, e->d_cls,
+    void *ptrs[] = {e->d_cond, e->d_dc_seg_end, e->d_dc_seg_in, e->d_dc_state, e->d_dc_partial, e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps, e->d_cls,
                     e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_out,
                     e->d_fft_stage, e->d_fft_Y, e->d_tw4096, e->d_tw_lo, e->d_tw_hi, e->d_window, e->d_fft_avg, e->d_band,
                     e->d_meter, e->d_graph, e->d_pix, e->d_k0};
@@ -1442,6 +1499,23 @@ int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int
     e->ntaps[rx] = n; e->bandwidth[rx] = bandwidth; e->start_offset[rx] = start_offset;
     const int cl = class_of_mode(e->mode[rx], bandwidth);      // DGT-U/L change chain with the bandwidth
     if (cl >= 0 && cl != e->cls[rx]) { e->cls[rx] = cl; return upload_members(e); }
+    return QK_OK;
+}
+
+int qk_set_dc_remove(qk_engine *e, int bandwidth)
+{
+    ENGINE_ENTER(e);
+    if (bandwidth < 0) return fail(QK_EINVAL, "bad DC removal bandwidth");
+    SYNC_ALL(e);
+    e->dc_bw = bandwidth;
+    return QK_OK;
+}
+
+int qk_set_invert_spectrum(qk_engine *e, int on)
+{
+    ENGINE_ENTER(e);
+    SYNC_ALL(e);
+    e->invert = on != 0;
     return QK_OK;
 }
 

@@ -1135,6 +1135,124 @@ __global__ __launch_bounds__(256) void k_unpack_int(const unsigned char *raw, do
 }
 
 // ------------------------------------------------------------------------------------------------
+// Input conditioning on the full-rate stream, in front of the spectrum and the mixer:
+//   DCremove (sound.c:165-230), bandwidth > 1: c = x + dc alpha; y = c - dc; dc = c  (R. G. Lyons' DC blocker),
+//   bandwidth == 1: y = x - dc_average, the average taken over two-second stretches (sound.c:198-222);
+//   spectrum inversion (quisk.c:2315-2320): conjugate, applied behind the DC removal.
+// The recurrence is one serial chain over the whole stream in the reference.  Here it is the same scan as
+// k_serial_iir, over segments of 1024 samples: pass 0 finds every segment's end value from a zero state, a
+// single wave chains the segment ends (k_dc_chain), pass 1 redoes the segment from its true start value and writes.
+// Rounding order differs from the serial walk; alpha < 1, so the differences stay at the 1e-16 level.
+// ------------------------------------------------------------------------------------------------
+#define DC_K 16
+#define DC_SEG (64 * DC_K)
+struct DcArgs {
+    const double2 *x; double2 *y; int n;
+    double alpha, alpha_seg;       // alpha^DC_SEG
+    double2 *seg_end;              // [nseg] pass 0 -> chain
+    const double2 *seg_in;         // [nseg] chain -> pass 1
+    int conj_out;
+};
+template <int PASS>
+__global__ __launch_bounds__(64) void k_dc_iir(DcArgs a)
+{
+#pragma clang fp contract(off)
+    const int seg = blockIdx.x, lane = threadIdx.x;
+    const int base = seg * DC_SEG + lane * DC_K;
+    int v = a.n - base;
+    v = v < 0 ? 0 : (v > DC_K ? DC_K : v);
+    double pw[DC_K];
+    pw[0] = a.alpha;
+#pragma unroll
+    for (int k = 1; k < DC_K; k++) pw[k] = pw[k - 1] * a.alpha;
+    double2 x[DC_K];
+#pragma unroll
+    for (int k = 0; k < DC_K; k++) x[k] = k < v ? a.x[base + k] : make_double2(0.0, 0.0);
+    double2 l = make_double2(0.0, 0.0), lend = l;
+    double fl = 1.0;
+#pragma unroll
+    for (int k = 0; k < DC_K; k++) {
+        l = make_double2(x[k].x + l.x * a.alpha, x[k].y + l.y * a.alpha);
+        x[k] = l;
+        if (k < v) { lend = l; fl = pw[k]; }
+    }
+    double2 Sin = make_double2(0.0, 0.0), run = PASS ? a.seg_in[seg] : make_double2(0.0, 0.0);
+    for (int L = 0; L < 64; L++) {
+        if (lane == L) Sin = run;
+        const double f = readlane_f64(fl, L);
+        run = make_double2(readlane_f64(lend.x, L) + f * run.x, readlane_f64(lend.y, L) + f * run.y);
+    }
+    if (PASS == 0) {
+        if (lane == 0) a.seg_end[seg] = run;
+    } else {
+        double2 dprev = Sin;
+#pragma unroll
+        for (int k = 0; k < DC_K; k++) {
+            const double2 d = make_double2(x[k].x + pw[k] * Sin.x, x[k].y + pw[k] * Sin.y);
+            double2 y = make_double2(d.x - dprev.x, d.y - dprev.y);
+            if (a.conj_out) y.y = -y.y;
+            if (k < v) a.y[base + k] = y;
+            dprev = d;
+        }
+    }
+}
+// seg_in[s] = the recurrence state in front of segment s; *state carries over to the next block.  alpha_last = alpha^(length
+// of the last, possibly partial, segment).
+__global__ __launch_bounds__(64) void k_dc_chain(const double2 *seg_end, double2 *seg_in, int nseg, double alpha_seg, double alpha_last,
+                                                 double2 *state)
+{
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x;
+    double2 run = *state;
+    for (int s0 = 0; s0 < nseg; s0 += 64) {
+        const int s = s0 + lane;
+        const double2 e = s < nseg ? seg_end[s] : make_double2(0.0, 0.0);
+        double2 mine = run;
+        const int cnt = nseg - s0 < 64 ? nseg - s0 : 64;
+        for (int L = 0; L < cnt; L++) {
+            if (lane == L) mine = run;
+            const double f = (s0 + L == nseg - 1) ? alpha_last : alpha_seg;
+            run = make_double2(readlane_f64(e.x, L) + f * run.x, readlane_f64(e.y, L) + f * run.y);
+        }
+        if (s < nseg) seg_in[s] = mine;
+    }
+    if (lane == 0) *state = run;
+}
+// y = (x - avg) [conj];  avg may be null (inversion only)
+__global__ __launch_bounds__(256) void k_dc_sub(const double2 *x, double2 *y, int n, const double2 *avg, int conj_out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double2 v = x[i];
+    if (avg) { const double2 m = *avg; v.x -= m.x; v.y -= m.y; }
+    if (conj_out) v.y = -v.y;
+    y[i] = v;
+}
+// dc_sum += sum of the block (sound.c:209-210), two deterministic stages: 256 partial sums, then one wave adds them in order
+__global__ __launch_bounds__(256) void k_dc_partial(const double2 *x, int n, double2 *partial)
+{
+    __shared__ double2 red[256];
+    double2 acc = make_double2(0.0, 0.0);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { acc.x += x[i].x; acc.y += x[i].y; }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[threadIdx.x].x += red[threadIdx.x + o].x; red[threadIdx.x].y += red[threadIdx.x + o].y; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// mode: 0 = add the partials to *sum; 1 = also close the stretch: *avg = *sum / count, *sum = 0 (sound.c:211-217)
+__global__ void k_dc_final(const double2 *partial, int np, double2 *sum, double2 *avg, int close_stretch, double count)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    double2 s = *sum;
+    for (int i = 0; i < np; i++) { s.x += partial[i].x; s.y += partial[i].y; }
+    if (close_stretch) { *avg = make_double2(s.x / count, s.y / count); s = make_double2(0.0, 0.0); }
+    *sum = s;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stand-alone FIR over interleaved complex samples for the filter.c drop-ins (quisk_cDecimate, filter.c:180-206;
 // quisk_cCDecimate, filter.c:208-234).  x holds ntaps-1 history samples followed by the new block.
 // ------------------------------------------------------------------------------------------------

@@ -60,6 +60,8 @@ def lib():
     L.qk_audio_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.qk_get_graph.argtypes = [vp, C.c_double, C.c_double, vp, C.c_int, dp]
     L.qk_graph_pending.argtypes = [vp]
+    L.qk_set_dc_remove.argtypes = [vp, C.c_int]
+    L.qk_set_invert_spectrum.argtypes = [vp, C.c_int]
     L.qk_multirx_graph.argtypes = [vp, vp, C.c_int, vp]
     L.qk_bandscope_init.argtypes = [vp, C.c_int]
     L.qk_add_bscope_samples.argtypes = [vp, vp, C.c_int]
@@ -147,6 +149,13 @@ class Engine:
 
     def set_agc(self, rx, gain):
         _check(self.L.qk_set_agc(self.h, rx, float(gain)))
+
+    def set_dc_remove(self, bandwidth):
+        """dc_remove_bw of DCremove (sound.c:165-230): 0 off, 1 running average, > 1 one-pole blocker of that bandwidth."""
+        _check(self.L.qk_set_dc_remove(self.h, int(bandwidth)))
+
+    def set_invert_spectrum(self, on):
+        _check(self.L.qk_set_invert_spectrum(self.h, int(bool(on))))
 
     def set_agc_release_time(self, seconds):
         _check(self.L.qk_set_agc_release_time(self.h, float(seconds)))

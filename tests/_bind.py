@@ -56,6 +56,12 @@ class OGraph(C.Structure):
                 ("rx_tune", C.c_int), ("filter_start_offset", C.c_int), ("filter_bandwidth", C.c_int)]
 
 
+class ODcRemove(C.Structure):
+    _fields_ = [("old_sample_rate", C.c_int), ("old_bandwidth", C.c_int), ("alpha", C.c_double),
+                ("dc_remove", C.c_double * 2), ("dc_average", C.c_double * 2), ("dc_sum", C.c_double * 2),
+                ("dc_count", C.c_int), ("dc_key_delay", C.c_int)]
+
+
 class OBscope(C.Structure):
     _fields_ = [("size", C.c_int), ("count", C.c_int), ("window", c_dp), ("avg", c_dp), ("the_max", C.c_double)]
 
@@ -112,6 +118,9 @@ def oracle():
     L.qko_fracdecim.argtypes = [P(OFrac), cdp, C.c_int, C.c_double]
     L.qko_fft.argtypes = [cdp, C.c_int]
     L.qko_multirx_graph.argtypes = [cdp, C.c_int, ddp]
+    L.qko_dcremove_init.argtypes = [P(ODcRemove)]
+    L.qko_dcremove.argtypes = [P(ODcRemove), cdp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.qko_invert_spectrum.argtypes = [cdp, C.c_int]
     L.qko_bscope_init.argtypes = [P(OBscope), C.c_int]
     L.qko_bscope_free.argtypes = [P(OBscope)]
     L.qko_bscope_add.argtypes = [P(OBscope), ddp]
@@ -307,3 +316,21 @@ class OracleBscope:
 
     def close(self):
         self.L.qko_bscope_free(C.byref(self.b))
+
+
+class OracleConditioner:
+    """DCremove (sound.c:165-230) then spectrum inversion (quisk.c:2315-2320), as the reference applies them in front of
+    the FFT staging and the mixer."""
+
+    def __init__(self, sample_rate, dc_remove_bw=0, invert=False):
+        self.L = oracle()
+        self.fs, self.bw, self.invert = sample_rate, dc_remove_bw, invert
+        self.d = ODcRemove()
+        self.L.qko_dcremove_init(C.byref(self.d))
+
+    def __call__(self, x):
+        y = np.array(x, dtype=np.complex128, copy=True)
+        self.L.qko_dcremove(C.byref(self.d), y, len(y), self.fs, self.bw, 0)
+        if self.invert:
+            self.L.qko_invert_spectrum(y, len(y))
+        return y

@@ -1,0 +1,86 @@
+"""Input conditioning on the full-rate stream -- DCremove (sound.c:165-230) and spectrum inversion (quisk.c:2315-2320) --
+on the GPU against the oracle, seen through what follows it: the front end's output (mixer + half-bands; tolerance 1e-9
+of the peak), the demodulated audio and the spectrum row.  The one-pole DC blocker is one serial chain over the whole
+stream in the reference and a segmented scan here (different rounding order, alpha < 1)."""
+import numpy as np
+import pytest
+
+import _bind as B
+from _rxsetup import PairRunner, TOL
+from quisk_amd import Engine
+from quisk_amd.engine import TAP_FRONTEND
+from quisk_amd.synth import make_iq
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(fs, mode, tune, sizes, dc_bw, invert, seed, offset=(3.0e6 + 1.5e6j)):
+    x = make_iq(sum(sizes), fs, [tune, -tune // 2], [mode, mode], seed) + offset
+    eng = Engine(fs, n_receivers=1, max_block=max(sizes), fft_size=4096, data_width=1024)
+    pr = PairRunner(eng, [mode], [tune])
+    eng.set_dc_remove(dc_bw)
+    eng.set_invert_spectrum(invert)
+    cond = B.OracleConditioner(fs, dc_bw, invert)
+    og = B.OracleGraph(4096, 1024, fs)
+    from _rxsetup import rx_filter
+    _, _, bw, off = rx_filter(fs, mode)
+    og.set_passband(tune, off, bw)
+    pos, frames = 0, []
+    for s in sizes:
+        blk = x[pos:pos + s]
+        pos += s
+        yb = cond(blk)
+        frames.append(yb)
+        # PairRunner.step feeds the engine `blk` and the oracle receivers the conditioned block
+        eng.process(blk)
+        for r, o in enumerate(pr.oras):
+            pre_o, fin_o = o.process_parts(yb)
+            pre_g = eng.tap(4, r, planes=1)[0]
+            assert len(pre_g) == len(pre_o)
+            if len(pre_o):
+                pr.samples += len(pre_o)
+                pr.peak[r] = max(pr.peak[r], float(np.max(np.abs(pre_o.real))))
+                pr.pre_err = max(pr.pre_err, float(np.max(np.abs(pre_g - pre_o.real))) / max(pr.peak[r], 1.0))
+    allx = np.concatenate(frames)
+    nfr = len(allx) // 4096
+    og.add_frames(allx[:nfr * 4096])
+    n1, row1, sm1 = eng.get_graph(1.0, 0.0)
+    n2, row2, sm2 = og.release(1.0, 0.0)
+    assert n1 == n2 == nfr
+    assert np.max(np.abs(row1 - row2)) < 1e-7 and abs(sm1 - sm2) < 1e-7
+    assert pr.samples > 0 and pr.pre_err < TOL, pr.pre_err
+    pr.close(); og.close()
+
+
+@pytest.mark.parametrize("dc_bw,invert", [(100, False), (100, True), (0, True), (20, False), (1000, True)])
+def test_dc_blocker_and_inversion(dc_bw, invert):
+    _run(192000, 3, 21000, [9600, 4097, 12000, 999, 9600, 9600, 2048], dc_bw, invert, 17)
+
+
+def test_dc_blocker_long_blocks_at_1536k():
+    """Blocks longer than many scan segments, ragged lengths (a partial last segment and lane)."""
+    _run(1536000, 3, 300000, [65536, 100001, 1023, 1025, 65536], 100, False, 3)
+
+
+def test_dc_average_mode():
+    """dc_remove_bw == 1: nothing is subtracted during the first second, then the average of each two-second stretch."""
+    fs = 48000
+    _run(fs, 3, 5000, [12000] * 18, 1, False, 9)
+
+
+def test_dc_blocker_removes_the_offset():
+    fs = 192000
+    eng = Engine(fs, n_receivers=0, max_block=65536, fft_size=4096, data_width=4096)
+    eng.set_dc_remove(100)
+    x = make_iq(65536 * 2, fs, [30000], [3], 1) + (5.0e7 + 0j)
+    eng.process(x[:65536]); eng.get_graph()
+    eng.process(x[65536:])
+    n, row, _ = eng.get_graph()
+    dc_bin = row[2048]
+    eng2 = Engine(fs, n_receivers=0, max_block=65536, fft_size=4096, data_width=4096)
+    eng2.process(x[:65536]); eng2.get_graph()
+    eng2.process(x[65536:])
+    _, row2, _ = eng2.get_graph()
+    assert row2[2048] - dc_bin > 40.0            # the carrier at DC is gone (more than 40 dB down)
+    assert abs(row[2048 + 640] - row2[2048 + 640]) < 0.05      # the 30 kHz tone is untouched
+    eng.close(); eng2.close()
