@@ -23,6 +23,7 @@ What maps to what
         -> None until 1/graph_refresh seconds have passed and at least one frame is averaged (quisk.c:4712)
   get_multirx_graph(), add_bscope_samples(buffer), get_bandscope(clock, zoom, deltaf)           quisk.c:4468-4600, 2841-2900
   get_filter_rate(mode, bw), get_smeter(), get_state(), get_overrange()                         quisk.c:2661, 2737, 2618
+  set_sparams(dc_remove_bw=), invert_spectrum(i)                                                sound.c:1253, quisk.c:4174
 Audio goes to the sound card in the reference (quisk_play_*); here the last block of every receiver is kept and
 `get_audio(rx)` returns it (an addition: there is no such call in the reference).
 Everything else in QuiskMethods that is outside the path is accepted and ignored (INERT below).
@@ -354,15 +355,26 @@ def get_overrange():
     return n
 
 
+def set_sparams(**kw):
+    """sound.c:1253-1262: dc_remove_bw (and digital_output_level, which is off the path)."""
+    if "dc_remove_bw" in kw:
+        _st().eng.set_dc_remove(int(kw["dc_remove_bw"]))
+
+
+def invert_spectrum(on):
+    """quisk.c:4174-4182."""
+    _st().eng.set_invert_spectrum(int(on))
+
+
 def _inert(*args, **kw):
     return None
 
 
 # Entries of QuiskMethods outside the receive path: accepted and ignored.
 INERT = ("set_volume", "set_squelch", "set_ssb_squelch", "set_noise_blanker", "set_auto_notch", "set_kill_audio",
-         "set_split_rxtx", "set_multirx_play_method", "set_multirx_play_channel", "set_enable_bandscope", "invert_spectrum",
+         "set_split_rxtx", "set_multirx_play_method", "set_multirx_play_channel", "set_enable_bandscope",
          "add_tone", "set_spot_level", "set_imd_level", "set_key_down", "set_ctcss", "set_tx_audio", "set_record_state",
-         "set_file_name", "set_sidetone", "set_sparams", "set_transmit_mode", "set_fdx", "set_sample_bytes",
+         "set_file_name", "set_sidetone", "set_transmit_mode", "set_fdx", "set_sample_bytes",
          "change_rate", "change_rates", "change_scan", "start_sound", "open_sound", "open_key", "close_key",
          "open_rx_udp", "close_rx_udp", "set_hermes_id", "set_hermes_filters", "set_alex_hpf", "set_alex_lpf",
          "set_hermeslite_writepointer", "clear_hermeslite_response", "set_hermeslite_writequeue", "pc_to_hermes",
