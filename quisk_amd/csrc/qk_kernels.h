@@ -364,13 +364,26 @@ __device__ __forceinline__ void fw_carry(double *smem, int s, int n_new, int lan
 }
 
 template <int S, int s>
-__device__ __forceinline__ void fw_stage(double *smem, int c, int lane, bool emit, double *out0, double *out1, long long obase)
+__device__ __forceinline__ void fw_stage(double *smem, int c, int lane, bool emit, double *out0, double *out1, long long obase, long long dummy,
+                                         double (&pend_y)[FwLayout::R(S - 1)], long long (&pend_i)[FwLayout::R(S - 1)])
 {
     constexpr int R = FwLayout::R(s);
     const int n_out = c >> (s + 1);
     const int plane = lane >> 5, q = lane & 31;
     const int m0 = q * R;
-    if (m0 < n_out) {
+    if constexpr (s + 1 == S) {
+        // last level: every lane computes (idle lanes read padding) and hands its outputs to the chunk loop, which stores
+        // them one chunk later -- real outputs to the stream, the rest to the spare slot at its end: a fixed number of
+        // stores per chunk, issued in front of the next prefetch
+        double y[R];
+        hb45_out<R>(fw_arr(smem, s, plane, 1), fw_arr(smem, s, plane, 0), m0 < FW_CHUNK ? m0 : 0, y);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const bool ok = emit && m0 + r < n_out;
+            pend_y[r] = y[r];
+            pend_i[r] = ok ? obase + m0 + r : dummy;
+        }
+    } else if (m0 < n_out) {
         double y[R];
         hb45_out<R>(fw_arr(smem, s, plane, 1), fw_arr(smem, s, plane, 0), m0, y);
         if constexpr (s + 1 < S) {
@@ -407,6 +420,7 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
     const int mix = a.mt.mix_on[rx];
     const double2 *histp = a.hist + (long long)rx * a.H;
     double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
+    const long long dummy = (long long)a.out.plane_stride - a.out.hist - 1;     // last slot of the plane: never a sample
   for (int span = blockIdx.x; span < a.nspans; span += gridDim.x) {
     const long long g_lo = a.g_lo0 + (long long)span * a.span_len;
     if (g_lo >= a.g_end) break;
@@ -431,17 +445,31 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
     }
     // prefetch of the first chunk
     double2 xv[NIT];
+    // Every global access of the chunk loop is unconditional (clamped index, validity kept as a bit; stores of lanes
+    // with nothing to emit go to a spare slot at the end of the stream): the compiler can then count loads and
+    // stores in flight (s_waitcnt vmcnt(n)) instead of draining the queue -- a drained queue made every chunk wait
+    // for the previous chunk's stores to be acknowledged by memory.
+    unsigned okbits = 0;
     auto fetch = [&](long long p, int c) {
         const long long k0 = p - a.N0;
+        if (k0 >= 0 && c == FW_CHUNK) {          // whole chunk inside this block: no clamps, no validity bits
+            const double2 *src = a.x + k0 + lane;
+#pragma unroll
+            for (int it = 0; it < NIT; it++) xv[it] = src[64 * it];
+            okbits = (1u << NIT) - 1;
+            return;
+        }
+        okbits = 0;
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const int i = lane + 64 * it;
             const long long k = k0 + i;
-            xv[it] = make_double2(0.0, 0.0);
-            if (i < c) {
-                if (k >= 0) xv[it] = a.x[k];
-                else { const long long hi = k + a.H; if (hi >= 0) xv[it] = histp[hi]; }
-            }
+            const long long hi = k + a.H;
+            const bool in_blk = k >= 0;
+            const double2 *src = in_blk ? a.x : histp;
+            long long idx = in_blk ? (k < a.n ? k : (long long)a.n - 1) : (hi > 0 ? hi : 0);
+            xv[it] = src[idx];
+            if (i < c && (in_blk || hi >= 0)) okbits |= 1u << it;
         }
     };
     auto chunk_len = [&](long long p) -> int {
@@ -451,33 +479,60 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
     int c = chunk_len(pos);
     fetch(pos, c);
     __syncthreads();
+#ifdef FE_PROF
+    long long fp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fp_last = clock64(), fp_n = 0;
+#define FE_PROBE(k) do { const long long t_ = clock64(); fp[k] += t_ - fp_last; fp_last = t_; } while (0)
+#else
+#define FE_PROBE(k) do { } while (0)
+#endif
+    constexpr int RL = FwLayout::R(S - 1);
+    double pend_y[RL];
+    long long pend_i[RL];
+#pragma unroll
+    for (int r = 0; r < RL; r++) { pend_y[r] = 0.0; pend_i[r] = dummy; }
+    double *obase_p = (lane >> 5) ? out1 : out0;
     while (pos < g_hi) {
+        FE_PROBE(7);
         const bool emit = pos >= g_lo;
         const long long k0 = pos - a.N0;
         // ---- mix the prefetched samples into level 0 ----
+        if (k0 >= 0 && c == FW_CHUNK && mix) {      // the common case, free of per-sample conditions
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int i = lane + 64 * it;
-            if (i < c) {
-                double2 v = xv[it];
-                if (k0 + i >= 0 && mix) { v = cmul(v, w); w = cmul(w, P64); }
+            for (int it = 0; it < NIT; it++) {
+                const double2 v = cmul(xv[it], w);
+                w = cmul(w, P64);
                 d0[dofs + 32 * it] = v.x; d1[dofs + 32 * it] = v.y;
             }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int i = lane + 64 * it;
+                if (i < c) {
+                    double2 v = (okbits >> it & 1u) ? xv[it] : make_double2(0.0, 0.0);
+                    if (k0 + i >= 0 && mix) { v = cmul(v, w); w = cmul(w, P64); }
+                    d0[dofs + 32 * it] = v.x; d1[dofs + 32 * it] = v.y;
+                }
+            }
         }
-        // ---- next chunk's samples start their trip now ----
+        // ---- the previous chunk's outputs leave, then the next chunk's samples start their trip ----
+#pragma unroll
+        for (int r = 0; r < RL; r++) obase_p[pend_i[r]] = pend_y[r];
+
         const long long npos = pos + c;
         const int nc = npos < g_hi ? chunk_len(npos) : 0;
         if (nc > 0) fetch(npos, nc);
         __syncthreads();
+        FE_PROBE(0);
         const long long obase = (pos >> S) - a.J0;
         const bool full = c == FW_CHUNK;                 // partial chunks (warm-up tail, span end) take the safe path
-        fw_stage<S, 0>(smem, c, lane, emit, out0, out1, obase);
+        fw_stage<S, 0>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i);
         __syncthreads();
+        FE_PROBE(1);
         if (full) fw_carry(smem, 0, c >> 1, lane);
-        if constexpr (S > 1) { fw_stage<S, 1>(smem, c, lane, emit, out0, out1, obase); __syncthreads(); if (full) fw_carry(smem, 1, c >> 2, lane); }
-        if constexpr (S > 2) { fw_stage<S, 2>(smem, c, lane, emit, out0, out1, obase); __syncthreads(); if (full) fw_carry(smem, 2, c >> 3, lane); }
-        if constexpr (S > 3) { fw_stage<S, 3>(smem, c, lane, emit, out0, out1, obase); __syncthreads(); if (full) fw_carry(smem, 3, c >> 4, lane); }
-        if constexpr (S > 4) { fw_stage<S, 4>(smem, c, lane, emit, out0, out1, obase); __syncthreads(); if (full) fw_carry(smem, 4, c >> 5, lane); }
+        if constexpr (S > 1) { FE_PROBE(6); fw_stage<S, 1>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(2); if (full) fw_carry(smem, 1, c >> 2, lane); }
+        if constexpr (S > 2) { FE_PROBE(6); fw_stage<S, 2>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(3); if (full) fw_carry(smem, 2, c >> 3, lane); }
+        if constexpr (S > 3) { FE_PROBE(6); fw_stage<S, 3>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(4); if (full) fw_carry(smem, 3, c >> 4, lane); }
+        if constexpr (S > 4) { FE_PROBE(6); fw_stage<S, 4>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(5); if (full) fw_carry(smem, 4, c >> 5, lane); }
         if (!full) {
             // generic carry with a barrier between the reads and the writes (source and destination may overlap)
             constexpr int NC = S * 4 * FE_HIST;
@@ -505,6 +560,12 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
         __syncthreads();
         pos = npos; c = nc;
     }
+#pragma unroll
+    for (int r = 0; r < RL; r++) obase_p[pend_i[r]] = pend_y[r];
+#ifdef FE_PROF
+    if (lane == 0 && rx == 0 && span == 0)
+        printf("fe prof: mix %lld st0 %lld st1 %lld st2 %lld st3 %lld st4 %lld carry %lld looptail %lld\n", fp[0], fp[1], fp[2], fp[3], fp[4], fp[5], fp[6], fp[7]);
+#endif
   }
 }
 
