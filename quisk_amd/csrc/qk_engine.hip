@@ -1341,7 +1341,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             a.out = e->d_out; a.out_stride = (long long)e->out_stride;
             a.started = e->d_agc_started;
             Timer tm(e, QK_KT_AGC, e->agc_stream);
-            hipLaunchKernelGGL(k_agc_gain, dim3(e->nrx), dim3(64), 0, e->agc_stream, a);
+            hipLaunchKernelGGL(k_agc_gain, dim3(e->nrx), dim3(192), 0, e->agc_stream, a);
             hipLaunchKernelGGL(k_agc_apply, grid1(m_max, 1, e->nrx), dim3(256), 0, e->agc_stream, a);
             for (int cl = 0; cl < CL_COUNT; cl++) {
                 if (a.n_c[cl] <= 0) continue;

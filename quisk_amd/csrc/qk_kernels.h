@@ -951,85 +951,95 @@ __device__ __forceinline__ void agc_step(AgcState &s, const double m, const AgcC
     if (++s.index_read >= c.buf_size) s.index_read = 0;
 }
 
-__device__ __forceinline__ double wave_max_f64(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double w = __shfl_xor(v, o, 64);
-        v = v < w ? w : v;
-    }
-    return v;
-}
-
 // The serial part of a speculation pass: G_0 = g0, G_{k+1} = G_k * keep + add (MUL) or G_k + add (!MUL), and
-// lane L >= start must end up holding G_{L - start}, the gain in force at its sample.  Every lane runs the
-// same recurrence, and the EXEC mask retires one lane per step (exec <<= 1), so a lane simply stops at its own
-// value: two dependent FP64 operations per sample and nothing else on the vector pipe -- no selects, no LDS.
-// v_mul_f64 / v_add_f64 are the separately rounded operations of the reference (quisk.c:2112, 2117); the
-// compiler cannot express the shifting EXEC mask, hence the assembly.  `steps` = (last lane) - start >= 0.
+// lane L >= start must end up holding G_{L - start}, the gain in force at its sample (lanes below `start` keep
+// g0).  Every lane runs the same recurrence, and the EXEC mask retires one lane per step (exec <<= 1), so a lane
+// simply stops at its own value: two dependent FP64 operations per sample and nothing else on the vector pipe --
+// no selects, no LDS.  v_mul_f64 / v_add_f64 are the separately rounded operations of the reference
+// (quisk.c:2112, 2117); the compiler cannot express the shifting EXEC mask, hence the assembly.  The mask starts
+// shifted by `start`, and the chain leaves at a quarter mark once no lane is left.
 #define AGC_S1(MULOP) "s_lshl_b64 exec, exec, 1\n\t" MULOP "v_add_f64 %[g], %[g], %[t]\n\t"
-#define AGC_S8(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M)
-#define AGC_S63(M) AGC_S8(M) AGC_S8(M) AGC_S8(M) AGC_S8(M) AGC_S8(M) AGC_S8(M) AGC_S8(M) \
-                   AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M)
-#ifdef AGC_EXP
-#define AGC_MUL ""
-#else
-#define AGC_MUL "v_mul_f64 %[g], %[g], %[k]\n\t"
-#endif
+#define AGC_S4(M) AGC_S1(M) AGC_S1(M) AGC_S1(M) AGC_S1(M)
+#define AGC_S16(M) AGC_S4(M) AGC_S4(M) AGC_S4(M) AGC_S4(M)
+#define AGC_S15(M) AGC_S4(M) AGC_S4(M) AGC_S4(M) AGC_S1(M) AGC_S1(M) AGC_S1(M)
+#define AGC_CHAIN(M) "s_mov_b64 %[sv], exec\n\t" "s_lshl_b64 exec, exec, %[st]\n\t" \
+                     AGC_S16(M) "s_cbranch_execz 2f\n\t" AGC_S16(M) "s_cbranch_execz 2f\n\t" AGC_S16(M) "s_cbranch_execz 2f\n\t" \
+                     AGC_S15(M) "2:\n\t" "s_mov_b64 exec, %[sv]\n\t"
 template <bool MUL>
-__device__ __forceinline__ double agc_chain(double g0, double keep, double add, int start, int steps)
+__device__ __forceinline__ double agc_chain(double g0, double keep, double add, int start)
 {
     double gv = g0;
     unsigned long long save;
-    if (start == 0 && steps == 63) {
-        if (MUL)
-            asm volatile("s_mov_b64 %[sv], exec\n\t" AGC_S63(AGC_MUL) "s_mov_b64 exec, %[sv]\n\t"
-                         : [g] "+v"(gv), [sv] "=&s"(save) : [k] "v"(keep), [t] "v"(add) : "scc");
-        else
-            asm volatile("s_mov_b64 %[sv], exec\n\t" AGC_S63("") "s_mov_b64 exec, %[sv]\n\t"
-                         : [g] "+v"(gv), [sv] "=&s"(save) : [t] "v"(add) : "scc");
-    } else if (steps > 0) {
-        int n = steps;
-        if (MUL)
-            asm volatile("s_mov_b64 %[sv], exec\n\t"
-                         "s_lshl_b64 exec, %[sv], %[st]\n"
-                         "1:\n\t" AGC_S1(AGC_MUL)
-                         "s_sub_u32 %[n], %[n], 1\n\t"
-                         "s_cmp_lg_u32 %[n], 0\n\t"
-                         "s_cbranch_scc1 1b\n\t"
-                         "s_mov_b64 exec, %[sv]\n\t"
-                         : [g] "+v"(gv), [n] "+s"(n), [sv] "=&s"(save) : [k] "v"(keep), [t] "v"(add), [st] "s"(start) : "scc");
-        else
-            asm volatile("s_mov_b64 %[sv], exec\n\t"
-                         "s_lshl_b64 exec, %[sv], %[st]\n"
-                         "1:\n\t" AGC_S1("")
-                         "s_sub_u32 %[n], %[n], 1\n\t"
-                         "s_cmp_lg_u32 %[n], 0\n\t"
-                         "s_cbranch_scc1 1b\n\t"
-                         "s_mov_b64 exec, %[sv]\n\t"
-                         : [g] "+v"(gv), [n] "+s"(n), [sv] "=&s"(save) : [t] "v"(add), [st] "s"(start) : "scc");
-    }
+    if (MUL)
+        asm volatile(AGC_CHAIN("v_mul_f64 %[g], %[g], %[k]\n\t")
+                     : [g] "+v"(gv), [sv] "=&s"(save) : [k] "v"(keep), [t] "v"(add), [st] "s"(start) : "scc");
+    else
+        asm volatile(AGC_CHAIN("")
+                     : [g] "+v"(gv), [sv] "=&s"(save) : [t] "v"(add), [st] "s"(start) : "scc");
     return gv;
 }
 
-// One WAVE per receiver.  The state machine is serial in time, but almost every sample takes one of two
+// One slot of the runner's ring, written by one lane with two 16-byte stores, the tag in the second
+struct __attribute__((aligned(16))) AgcSlot {
+    double add, end;            // step constant at the tile's first sample; gain after its last
+    double add1;                // \ only for a tile that is not PLAIN (not clipping, no window boundary in it):
+    int bl, clip;               // / step constant behind the boundary, the boundary's lane (64: none), the path
+    int tag;                    // plain << 31 | generation << 20 | tile, -1 nothing
+    int pad[3];
+};
+// Three WAVES per receiver.  The state machine is serial in time, but almost every sample takes one of two
 // trivial paths: "not clipping, no new clip, not at the window boundary" (gain = gain*(1-tr) + target*tr,
-// themax = max(themax, m)) or "clipping, no new maximum, ramp not finished" (gain -= delta).  The wave
-// therefore runs a tile of 64 samples SPECULATIVELY down the current path (agc_chain) and then tests all 64
-// samples for an event (clip start, window boundary, new maximum, end of ramp) in one lane-parallel pass.
-// Samples in front of the first event are committed, the event sample goes through the full state machine
-// (agc_step), and speculation restarts behind it.  Every floating-point operation is the reference's own,
-// in its order, without FMA contraction: the result is bit-identical to a sample-by-sample walk (tests
-// check it against the oracle).
-__global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
+// themax = max(themax, m)) or "clipping, no new maximum, ramp not finished" (gain -= delta).  A tile of 64
+// samples is therefore run SPECULATIVELY down the current path (agc_chain: 63 dependent steps, about 350 ns,
+// the floor of this kernel) and then tested for an event (clip start, window boundary, new maximum,
+// end of ramp) in one lane-parallel pass; samples in front of the first event are committed, the event sample
+// goes through the full state machine (agc_step), and speculation restarts behind it.
+//   wave 0 (the runner) runs the chains, tile after tile, each continuing from the end of the one before as if
+//     no CLIP event happened.  Window boundaries it foresees itself: their position is a counter, and the new
+//     target needs only the maximum of |x| over the window, which it tracks like the walker does (max is exact:
+//     no rounding to reproduce); the tile with the boundary in it is chained in two parts, with the step
+//     constant before and after.  It leaves the 64 gains of a tile in a ring of AGC_RING slots in LDS together
+//     with what it assumed (step constants, boundary lane, path) and the gain it ends with;
+//   wave 1 (the walker) owns the state and never runs a chain.  It takes the runner's gains from sample `start`
+//     of a tile on whenever its own state there is the one the runner's chain passed through, bit for bit (the
+//     same instructions on the same operands: the same values), which also holds behind an event that left gain
+//     and target where they would have been (a window boundary whose new target equals the old one).  Otherwise
+//     it posts the true state and where it holds (a RESTART: tile, first sample) and waits for the runner to
+//     make that tile again from there;
+//   wave 2 (the fetcher) brings |x| into LDS a chunk of AGC_CHUNK tiles ahead: a trip to memory under the front
+//     end's load is several tiles long, and nobody waits for it here.
+// The waves hand over through tags and counters in LDS that the consumer polls (no barrier: the runner never
+// waits for the walker unless the ring is full).  Every floating-point operation is the reference's own, in its
+// order, without FMA contraction: the result is bit-identical to a sample-by-sample walk (tests check it against
+// the oracle).  Every poll is bounded: a wave that waits AGC_SPIN_LIMIT polls gives up and the walker poisons
+// the state (NaN gain) rather than hang the GPU.  Control flow is kept flat on purpose (one loop, one chain of
+// ifs, no early exits): a taken branch costs this single wave some twenty cycles, and the compiler's loop-exit
+// unification turns `continue` / `return` into many of them.
+#define AGC_RING 4
+#define AGC_CHUNK 32
+#define AGC_SPIN_LIMIT (1 << 22)
+#define AGC_LDS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+__global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
 {
 #pragma clang fp contract(off)
+    __shared__ double sp_gv[AGC_RING][64];          // runner -> walker: the gains of tile k in slot k % AGC_RING
+    __shared__ AgcSlot sp_rec[AGC_RING];            // ... what it assumed and what it ends with, and the tag that says so
+    __shared__ int wstat;                           // walker -> runner, fetcher: restart generation << 20 | tiles finished
+    __shared__ int fetched;                         // fetcher -> walker: chunks in LDS
+    __shared__ double rs_g, rs_add, rs_max;         // walker -> runner, with a new generation: the true state at sample
+                                                    // rs_start of tile rs_tile
+    __shared__ int rs_clip, rs_tile, rs_start, rs_ir, rs_is;
+    __shared__ int aborted;
+    __shared__ double sm[2][AGC_CHUNK * 64];        // fetcher -> walker: |x| of chunk c in buffer c & 1
     const int rx = blockIdx.x;
     const int cl = a.cls[rx];
     const int n_new = a.n_c[cl];
-    if (!a.started[rx] || n_new <= 0) return;
-    __builtin_amdgcn_s_setprio(3);      // a latency-bound wave among the front end's throughput-bound ones: issue first
-    const int lane = threadIdx.x;
+    if (!a.started[rx] || n_new <= 0) return;       // (the whole workgroup)
+    if (threadIdx.x < AGC_RING) sp_rec[threadIdx.x].tag = -1;
+    if (threadIdx.x == 0) { wstat = 0; fetched = 0; aborted = 0; }
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(3);      // latency-bound waves among the front end's throughput-bound ones: issue first
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const double *__restrict__ p = sv_ptr(a.in_c[cl], rx, 0);
     double *__restrict__ g = a.gains + (long long)rx * a.gain_stride;
     AgcState s = a.state[rx];
@@ -1038,98 +1048,288 @@ __global__ __launch_bounds__(64) void k_agc_gain(AgcArgs a)
     c.bs = (double)a.buf_size; c.buf_size = a.buf_size;
     const int md = a.mode[rx];
     c.fm = (md == 5 || md == 13);
-    // The raw samples of the next two tiles are always in flight: a tile takes about as long as one trip to
-    // memory.  Loads and stores are unconditional (indices clamped, the gain rows are padded to whole tiles) so
-    // that the compiler can count them in flight instead of draining the queue; lanes past the end are never
-    // `mine`.  The tile loop is unrolled by hand by the depth of the rotation (three registers), so that no
-    // register copy has to wait for a load that was only just issued.
+    const int T = (n_new + 63) >> 6;                // tiles
     const int last = n_new - 1;
-#ifdef AGC_PROF
-    long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = clock64(), t_begin = t_last;
-#define AGC_PROBE(k) do { const long long t_ = clock64(); tp[k] += t_ - t_last; t_last = clock64(); tp[7] += t_last - t_; } while (0)
-#else
-#define AGC_PROBE(k) do { } while (0)
-#endif
-    auto tile = [&](const int i0, const double mv) {
-        AGC_PROBE(0);                                                   // tile loop: load issue, wait, magnitude
-        const int cnt = (n_new - i0 < 64) ? n_new - i0 : 64;
-        double gv = 0.0;                                               // gain in force at this lane's sample
-        int start = 0;
-        while (start < cnt) {
-            s.pad++;                                                    // statistics: speculation passes
-            const bool mine = lane >= start && lane < cnt;
-            bool ev;
-            int fmax = cnt;                                             // first sample that is an event for a wave-uniform reason
-            double gs, step_add;
-            if (!s.is_clipping) {
-                const double tt = s.target_gain * c.tr;
-                AGC_PROBE(1);
-                gs = agc_chain<true>(s.gain, c.keep, tt, start, cnt - 1 - start);
-                AGC_PROBE(2);                                           // the chain
-                if (lane >= start) gv = gs;
-                step_add = tt;
-                // the window boundary (index_read == index_start) falls on a lane known in advance
-                int ahead = s.index_start - s.index_read;
-                if (ahead < 0) ahead += a.buf_size;
-                if (start + ahead < cnt) fmax = start + ahead;
-                ev = mine && (mv * gv > c.ceil_);
-            } else {
-                const double dl = s.delta;
-                gs = agc_chain<false>(s.gain, 0.0, -dl, start, cnt - 1 - start);
-                if (lane >= start) gv = gs;
-                step_add = -dl;
-                ev = mine && ((mv > s.themax) || (gv - dl <= s.target_gain));
+    // the constant added per step on the current path
+    auto step_const = [&](const AgcState &st) { return st.is_clipping ? -st.delta : st.target_gain * c.tr; };
+    auto one_more = [&](double glast, double add, int clip) { return clip ? glast + add : glast * c.keep + add; };
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto tag_of = [](int gen, int tile) { return ((gen & 0x7ff) << 20) | tile; };
+    // the hand-over words: relaxed workgroup-scope atomics on LDS (read anew at every poll, plain ds_read / ds_write;
+    // `volatile` would turn them into system-scope FLAT accesses, a trip to memory each)
+    auto peek = [](int *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto poke = [](int *w, int v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+
+    if (wave == 0) {
+        // ---------------- the runner ----------------
+        // (j, st): the tile to make and its first sample; the state there: gain g0, step constant add, path clip,
+        // maximum rmax, ring indices ir / is (the walker's index_read / index_start)
+        int j = 0, st = 0, gen = 0, waits = 0, f_known = 0;
+        double g0 = s.gain, add = step_const(s), rmax = s.themax;
+        int clip = s.is_clipping, ir = s.index_read, is = s.index_start;
+        bool alive = true;
+        // max of |x| over the lanes in `in`, on top of m: walk the successive record holders (usually none)
+        auto walk_max = [&](double m, const double mv, const bool in) {
+            unsigned long long over = __ballot(in && mv > m);
+            while (over) {
+                m = readlane_f64(mv, (int)__ffsll((long long)over) - 1);
+                over = __ballot(in && mv > m);
             }
-            const unsigned long long mask = __ballot(ev);
-            int f = mask ? (int)__ffsll((long long)mask) - 1 : cnt;           // first event sample
-            if (fmax < f) f = fmax;
-            AGC_PROBE(3);                                               // event test
-            if (!s.is_clipping) {
-                // themax = max(themax, |x| of the committed samples): walk the successive record holders instead of
-                // reducing over the wave -- there are about ln(64) of them at worst on noise, usually none
-                const bool inr = lane >= start && lane < f;
-                unsigned long long over = __ballot(inr && mv > s.themax);
-                while (over) {
-                    s.themax = readlane_f64(mv, (int)__ffsll((long long)over) - 1);
-                    over = __ballot(inr && mv > s.themax);
+            return m;
+        };
+        auto hand_over = [&](const int jj, const double gs, const double a0, const double pend, const bool plain,
+                             const double a1, const int cl_, const int bl) {
+            const int slot = jj & (AGC_RING - 1);
+            // The tag goes last and nothing waits in between: the LDS executes one wave's instructions in the order
+            // they were issued, so whoever sees the tag sees the tile.  (The compiler is told not to reorder them.)
+            sp_gv[slot][lane] = gs;
+            if (lane == 0) {
+                sp_rec[slot].add = a0; sp_rec[slot].end = pend;
+                if (!plain) { sp_rec[slot].add1 = a1; sp_rec[slot].bl = bl; sp_rec[slot].clip = cl_; }
+                asm volatile("" ::: "memory");
+                poke(&sp_rec[slot].tag, tag_of(gen, jj) | (plain ? (int)0x80000000 : 0));
+            }
+        };
+        while (alive) {
+            if (j < T && j / AGC_CHUNK >= f_known) f_known = uni(peek(&fetched));   // (one look per chunk, as a rule)
+            bool can = j < T && j / AGC_CHUNK < f_known;
+            if (can && !clip && st == 0) {
+                // ---- the tight loop: the whole tiles in front of the window boundary, within the chunk in LDS.  A
+                // lone wave issues an instruction every four or five cycles at best: whatever is not the chain
+                // (850 cycles) is kept to a few dozen instructions here.
+                int ahead = is - ir;
+                if (ahead < 0) ahead += a.buf_size;
+                int jend = (j / AGC_CHUNK + 1) * AGC_CHUNK;
+                if (T < jend) jend = T;
+                if (j + (ahead >> 6) < jend) jend = j + (ahead >> 6);
+                const double *mp = &sm[(j / AGC_CHUNK) & 1][(j % AGC_CHUNK) * 64 + lane];
+                const int j0 = j;
+                while (j < jend) {
+                    const int ws_v = peek(&wstat);          // (asked for before the chain, looked at after it)
+                    const double mv = *mp;
+                    const double gs = agc_chain<true>(g0, c.keep, add, 0);
+                    const double pend = readlane_f64(gs, 63) * c.keep + add;
+                    const double nmax = walk_max(rmax, mv, true);
+                    // a restart (another generation in wstat) or the ring full: the general step deals with it
+                    if ((unsigned)(j - (uni(ws_v) - (gen << 20))) >= (unsigned)AGC_RING) break;
+                    hand_over(j, gs, add, pend, true, add, 0, 64);
+                    g0 = pend; rmax = nmax; ++j; mp += 64;
+                }
+                ir += (j - j0) << 6;
+                while (ir >= a.buf_size) ir -= a.buf_size;
+                if (j < T && j / AGC_CHUNK >= f_known) f_known = uni(peek(&fetched));
+                can = j < T && j / AGC_CHUNK < f_known;
+            }
+            // ---- the general step: one tile, whatever it holds
+            const int ws_v = peek(&wstat);
+            double gs = g0, pend = g0, add1 = add, nmax = rmax;
+            int bl = 64;
+            if (can) {
+                const double mv = sm[(j / AGC_CHUNK) & 1][(j % AGC_CHUNK) * 64 + lane];
+                int ahead = is - ir;                // samples from sample st to the window boundary
+                if (ahead < 0) ahead += a.buf_size;
+                if (clip) {
+                    gs = agc_chain<false>(g0, 0.0, add, st);
+                    pend = readlane_f64(gs, 63) + add;
+                } else if (st + ahead > 63) {       // no boundary in this tile
+                    gs = agc_chain<true>(g0, c.keep, add, st);
+                    pend = readlane_f64(gs, 63) * c.keep + add;
+                    nmax = walk_max(rmax, mv, lane >= st);
+                } else {                            // the boundary is sample bl: quisk.c:2095-2103 there, on the maximum so far
+                    bl = st + ahead;
+                    gs = agc_chain<true>(g0, c.keep, add, st);      // (right up to lane bl; the lanes behind are made again)
+                    nmax = walk_max(rmax, mv, lane >= st && lane < bl);
+                    const double clip_gain = c.ceil_ / nmax;
+                    const double tnew = c.fm ? clip_gain : (c.rel > clip_gain ? clip_gain : c.rel);
+                    add1 = tnew * c.tr;
+                    const double gnext = readlane_f64(gs, bl) * c.keep + add1;
+                    pend = gnext;
+                    if (bl < 63) {
+                        const double g2 = agc_chain<true>(gnext, c.keep, add1, bl + 1);
+                        if (lane > bl) gs = g2;
+                        pend = readlane_f64(g2, 63) * c.keep + add1;
+                    }
+                    nmax = walk_max(readlane_f64(mv, bl), mv, lane > bl);
                 }
             }
-            AGC_PROBE(4);                                               // window maximum
-            s.index_read += f - start;
-            if (s.index_read >= a.buf_size) s.index_read -= a.buf_size;
-            if (f >= cnt) {
-                const double glast = readlane_f64(gs, cnt - 1);        // gain in force at the last sample: one more step
-                s.gain = s.is_clipping ? glast + step_add : glast * c.keep + step_add;
-                start = cnt;
-            } else {
-                s.gain = readlane_f64(gv, f);
-                agc_step(s, readlane_f64(mv, f), c);
-                start = f + 1;
+            const int ws = uni(ws_v), w = ws & 0xfffff, rs = ws >> 20;
+            if (rs == gen && can && j - w < AGC_RING) {             // hand the tile over, go on behind it
+                hand_over(j, gs, add, pend, false, add1, clip, bl);
+                ir += 64 - st;
+                if (ir >= a.buf_size) ir -= a.buf_size;
+                g0 = pend; add = add1; rmax = nmax; st = 0; ++j;
+                waits = 0;
+            } else if (rs != gen) {                 // a restart: continue from the truth (the tile just made is dropped)
+                AGC_LDS_WAIT();
+                j = uni(rs_tile); st = uni(rs_start); clip = uni(rs_clip); ir = uni(rs_ir); is = uni(rs_is);
+                g0 = readlane_f64(rs_g, 0); add = readlane_f64(rs_add, 0); rmax = readlane_f64(rs_max, 0);
+                gen = rs;
+                waits = 0;
+            } else {                                // ring full, chunk not there yet, or all tiles made: the walker may still restart
+                if (j >= T && w >= T) alive = false;
+                __builtin_amdgcn_s_sleep(2);
+                if (++waits > AGC_SPIN_LIMIT || uni(peek(&aborted))) { poke(&aborted, 1); alive = false; }
             }
-            AGC_PROBE(5);                                               // commit / event step
         }
-        g[i0 + lane] = gv;
-        AGC_PROBE(6);
-    };
-    // (the prologue loads are consumed here, so the loop is entered with nothing in flight and its waits count
-    // only what the loop itself issued)
-    double ra = fabs(p[min(lane, last)]), rb = fabs(p[min(64 + lane, last)]), rc;
-    for (int i0 = 0; i0 < n_new; i0 += 192) {
-        rc = p[min(i0 + 128 + lane, last)];
-        tile(i0, fabs(ra));
-        if (i0 + 64 >= n_new) break;
-        ra = p[min(i0 + 192 + lane, last)];
-        tile(i0 + 64, fabs(rb));
-        if (i0 + 128 >= n_new) break;
-        rb = p[min(i0 + 256 + lane, last)];
-        tile(i0 + 128, fabs(rc));
+    } else if (wave == 1) {
+        // ---------------- the walker ----------------
+        int gen = 0;
+        bool dead = false;
+        double cur_add = step_const(s);             // its step constant: changes only on the general path
+        // what the slot of the current tile holds
+        double spec_gv = 0.0, sa = 0.0, sa1 = 0.0, se = 0.0;
+        int sc = 0, sb = 64;
+        // wait for tile k of the current generation, take it
+        auto acquire = [&](const int k) {
+            const int slot = k & (AGC_RING - 1);
+            const int want = tag_of(gen, k);
+            int spins = 0, tag = uni(peek(&sp_rec[slot].tag));
+            while (!dead && (tag & 0x7fffffff) != want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > AGC_SPIN_LIMIT || uni(peek(&aborted))) dead = true;
+                tag = uni(peek(&sp_rec[slot].tag));
+            }
+            asm volatile("" ::: "memory");          // (the tile's data is read after its tag, not before)
+            sa = sp_rec[slot].add; se = sp_rec[slot].end;
+            spec_gv = sp_gv[slot][lane];
+            sa1 = sa; sb = 64; sc = 0;              // a plain tile
+            if (tag >= 0) { sa1 = sp_rec[slot].add1; sb = sp_rec[slot].bl; sc = sp_rec[slot].clip; }
+        };
+        // ask the runner for tile k from sample `start` on, in the walker's state
+        auto restart = [&](const int k, const int start) {
+            ++gen;
+            if (lane == 0) {
+                rs_g = s.gain; rs_add = cur_add; rs_max = s.themax; rs_clip = s.is_clipping; rs_tile = k; rs_start = start;
+                rs_ir = s.index_read; rs_is = s.index_start;
+            }
+            AGC_LDS_WAIT();
+            if (lane == 0) poke(&wstat, tag_of(gen, k));
+        };
+        auto tile = [&](const int k) {
+            const double mv = sm[(k / AGC_CHUNK) & 1][(k % AGC_CHUNK) * 64 + lane];
+            const int i0 = k << 6;
+            const int cnt = (n_new - i0 < 64) ? n_new - i0 : 64;
+            // The common tile, at the least cost: the runner's gains are valid from sample 0, not clipping, a whole
+            // tile, the window boundary not in it and no clip: commit all 64 samples.  (Exactly what one pass of the
+            // loop below does; the gain after the tile is the runner's: the same operation on the same operands.
+            // The comparisons are lane-wise on wave-uniform values: every lane gets the same verdict.)
+            if (!s.is_clipping && cnt == 64) {
+                int ahead = s.index_start - s.index_read;
+                if (ahead < 0) ahead += a.buf_size;
+                const bool quiet = (sc == 0) & (sb == 64) & (sa == cur_add) & (readlane_f64(spec_gv, 0) == s.gain) &
+                                   !(mv * spec_gv > c.ceil_);
+                if (ahead >= 64 && __ballot(quiet) == ~0ull) {
+                    unsigned long long over = __ballot(mv > s.themax);
+                    while (over) {
+                        s.themax = readlane_f64(mv, (int)__ffsll((long long)over) - 1);
+                        over = __ballot(mv > s.themax);
+                    }
+                    s.pad++;
+                    s.index_read += 64;
+                    if (s.index_read >= a.buf_size) s.index_read -= a.buf_size;
+                    s.gain = se;
+                    g[i0 + lane] = spec_gv;
+                    return;
+                }
+            }
+            double gv = 0.0;                                            // gain in force at this lane's sample
+            int start = 0;
+            while (start < cnt && !dead) {
+                s.pad++;                                                // statistics: speculation passes
+                const bool mine = lane >= start && lane < cnt;
+                // The runner's gains serve from `start` on when the state there is the one its chain passed through at
+                // that sample (lane L holds the gain in force at sample L); if not, it makes the tile again from here.
+                // (Values read from LDS are per-lane to the compiler: the verdict is made wave-uniform.)
+                const bool spec_ok = uni((int)((sc == s.is_clipping) & ((start > sb ? sa1 : sa) == cur_add) &
+                                               (readlane_f64(spec_gv, start) == s.gain))) != 0;
+                if (!spec_ok) { restart(k, start); acquire(k); }
+                const double gs = spec_gv;
+                if (lane >= start) gv = gs;
+                bool ev;
+                int fmax = cnt;                                         // first sample that is an event for a wave-uniform reason
+                if (!s.is_clipping) {
+                    // the window boundary (index_read == index_start) falls on a lane known in advance
+                    int ahead = s.index_start - s.index_read;
+                    if (ahead < 0) ahead += a.buf_size;
+                    if (start + ahead < cnt) fmax = start + ahead;
+                    ev = mine && (mv * gv > c.ceil_);
+                } else {
+                    ev = mine && ((mv > s.themax) || (gv - s.delta <= s.target_gain));
+                }
+                // behind lane sb the runner's gains follow its second step constant: whatever the walker's own view of the
+                // window, it stops there and checks again (sample sb goes through agc_step: always right, only slower)
+                if (sb >= start && sb < fmax) fmax = sb;
+                const unsigned long long mask = __ballot(ev);
+                int f = mask ? (int)__ffsll((long long)mask) - 1 : cnt;       // first event sample
+                if (fmax < f) f = fmax;
+                if (!s.is_clipping) {
+                    // themax = max(themax, |x| of the committed samples): walk the successive record holders instead of
+                    // reducing over the wave -- there are about ln(64) of them at worst on noise, usually none
+                    const bool inr = lane >= start && lane < f;
+                    unsigned long long over = __ballot(inr && mv > s.themax);
+                    while (over) {
+                        s.themax = readlane_f64(mv, (int)__ffsll((long long)over) - 1);
+                        over = __ballot(inr && mv > s.themax);
+                    }
+                }
+                s.index_read += f - start;
+                if (s.index_read >= a.buf_size) s.index_read -= a.buf_size;
+                if (f >= cnt) {
+                    const double glast = readlane_f64(gs, cnt - 1);    // gain in force at the last sample: one more step
+                    s.gain = one_more(glast, cur_add, s.is_clipping);
+                    start = cnt;
+                } else {
+                    s.gain = readlane_f64(gv, f);
+                    agc_step(s, readlane_f64(mv, f), c);
+                    cur_add = step_const(s);
+                    start = f + 1;
+                }
+            }
+            g[i0 + lane] = gv;
+            // the runner went on from (se, sa1) on the same path: if that is not where the tile ended, it starts the next one
+            // again.  (Its window maximum is not compared: it follows the walker's by construction, and a wrong one would
+            // only make a wrong target at the next boundary, which is caught there like any other.)
+            if (!uni((int)((sc == s.is_clipping) & (sa1 == cur_add) & (se == s.gain))) && k + 1 < T) restart(k + 1, 0);
+        };
+        for (int k = 0; k < T && !dead; ++k) {
+            if (k % AGC_CHUNK == 0) {
+                int spins = 0;
+                while (!dead && uni(peek(&fetched)) <= k / AGC_CHUNK) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > AGC_SPIN_LIMIT || uni(peek(&aborted))) dead = true;
+                }
+            }
+            acquire(k);
+            if (!dead) tile(k);
+            if (lane == 0) poke(&wstat, tag_of(gen, k + 1));
+        }
+        if (dead) { poke(&aborted, 1); s.gain = __builtin_nan(""); }
+        if (lane == 0) { poke(&wstat, tag_of(gen, T)); a.state[rx] = s; }
+    } else {
+        // ---------------- the fetcher ----------------
+        // Loads are unconditional (indices clamped to the block; lanes past the end are never `mine`).
+        const int nch = (T + AGC_CHUNK - 1) / AGC_CHUNK;
+        double v[AGC_CHUNK];
+#pragma unroll
+        for (int u = 0; u < AGC_CHUNK; ++u) v[u] = p[min(u * 64 + lane, last)];
+        bool alive = true;
+        for (int ch = 0; ch < nch && alive; ++ch) {
+            // buffer ch & 1 is free once chunk ch-2 is walked
+            int spins = 0;
+            while (alive && (uni(peek(&wstat)) & 0xfffff) < (ch - 1) * AGC_CHUNK) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > AGC_SPIN_LIMIT || uni(peek(&aborted))) { poke(&aborted, 1); alive = false; }
+            }
+#pragma unroll
+            for (int u = 0; u < AGC_CHUNK; ++u) sm[ch & 1][u * 64 + lane] = fabs(v[u]);
+            AGC_LDS_WAIT();
+            if (lane == 0) poke(&fetched, ch + 1);
+            if (ch + 1 < nch) {                     // in flight while the walker works through chunk ch
+#pragma unroll
+                for (int u = 0; u < AGC_CHUNK; ++u) v[u] = p[min(((ch + 1) * AGC_CHUNK + u) * 64 + lane, last)];
+            }
+        }
     }
-#ifdef AGC_PROF
-    if (lane == 0 && rx == 0)
-        printf("agc prof: n %d total %lld | loop %lld pre %lld chain %lld event %lld max %lld commit %lld store %lld probe %lld\n", n_new,
-               (long long)(clock64() - t_begin), tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6], tp[7]);
-#endif
-    if (lane == 0) a.state[rx] = s;
 }
 __global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
 {
