@@ -32,7 +32,6 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 namespace {
 
-constexpr int FE_CHUNK = 1536;
 constexpr int DEFAULT_TAP_CAP = 1024;
 constexpr int EV_POOL = 2048;
 
@@ -110,7 +109,6 @@ struct qk_engine {
     int fe_slots = 2304;       // resident one-wave workgroups of k_frontend_wave on the whole chip (occupancy query)
     int fe_share = 100;        // percent of the resident slots the front end may occupy (QK_FE_SHARE)
     int fe_rounds = 2;         // front-end workgroups launched per resident slot (QK_FE_ROUNDS)
-    int fe_variant = 1;        // 1 = k_frontend_wave (one wave per span), 0 = k_frontend (256-thread workgroups); QK_FE_VARIANT
     int rate_case = 0;
     // input
     double2 *d_in = nullptr;
@@ -546,7 +544,6 @@ static int init_receivers(qk_engine *e)
     if (rc != QK_OK) return rc;
     // mixer state
     e->H = (44 << e->S) + (1 << e->S) + 128;
-    if (const char *v = getenv("QK_FE_VARIANT")) e->fe_variant = atoi(v) ? 1 : 0;
     if (const char *v = getenv("QK_FE_SHARE")) e->fe_share = std::max(5, std::min(100, atoi(v)));
     if (const char *v = getenv("QK_FE_ROUNDS")) e->fe_rounds = std::max(1, std::min(16, atoi(v)));
     {
@@ -603,6 +600,7 @@ static int init_receivers(qk_engine *e)
     e->agc_started.assign(nrx, 0);
     // output: the audio of one block at the play rate
     const long long per_block = (long long)cfg.max_block * cfg.playback_rate / cfg.sample_rate + 64;
+    if (per_block > (1LL << 26)) return fail(QK_ERANGE, "max_block gives more than 2^26 audio samples per block (k_agc_gain tile index)");
     e->out_stride = (size_t)((per_block + 63) & ~63LL);
     e->gain_stride = (int)e->out_stride;
     HIPCHECK(hipMalloc(&e->d_out, nrx * e->out_stride * sizeof(double2)));
@@ -1157,16 +1155,11 @@ static void add_tails(TailArgs &ta, Chain &c, int skip)
 template <int S>
 static void launch_frontend(qk_engine *e, const FrontArgs &fa, int nspans)
 {
-    if (e->fe_variant == 0) {
-        const size_t lds = FeLayout<FE_CHUNK>::total(S) * sizeof(double);
-        hipLaunchKernelGGL((k_frontend<S, FE_CHUNK>), dim3(nspans, e->nrx), dim3(FE_THREADS), lds, e->fe_stream, fa);
-    } else {
-        // a fixed number of workgroups per receiver walks the spans: with fe_share < 100 the front end leaves part of
-        // every CU's LDS and registers to the kernels of the other two streams
-        int gx = nspans;
-        if (e->fe_share < 100) gx = std::max(1, std::min(nspans, (int)((long long)e->fe_slots * e->fe_share / 100 / std::max(1, e->nrx))));
-        hipLaunchKernelGGL((k_frontend_wave<S>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
-    }
+    // a fixed number of workgroups per receiver walks the spans: with fe_share < 100 the front end leaves part of
+    // every CU's LDS and registers to the kernels of the other two streams
+    int gx = nspans;
+    if (e->fe_share < 100) gx = std::max(1, std::min(nspans, (int)((long long)e->fe_slots * e->fe_share / 100 / std::max(1, e->nrx))));
+    hipLaunchKernelGGL((k_frontend_wave<S>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
 }
 
 // DCremove and spectrum inversion in front of everything else; returns the buffer the rest of the block reads
@@ -1252,8 +1245,8 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         } else if (consumed > 0) {
             // spans: enough workgroups to fill 256 CUs several times over, but long enough that the warm-up
             // (44 * 2^S samples per span) stays a small fraction
-            const long long unit = e->fe_variant ? FW_CHUNK : FE_CHUNK;
-            const long long target_wgs = e->fe_variant ? (long long)e->fe_rounds * e->fe_slots : 2048;
+            const long long unit = FW_CHUNK;
+            const long long target_wgs = (long long)e->fe_rounds * e->fe_slots;
             long long want = std::max(1LL, target_wgs / std::max(1, e->nrx));
             long long span = (consumed + want - 1) / want;
             span = std::max(span, 4 * unit);

@@ -136,168 +136,13 @@ __global__ __launch_bounds__(256) void k_mixhist_update(FrontArgs a, double2 *hi
 // Global index convention: stage-s output j is emitted at input index 2^s j + 2^s - 1 (the reference
 // emits on every second input, toggle starting at 0).
 // ------------------------------------------------------------------------------------------------
-#define FE_THREADS 256
-#define FE_R 6
 #define FE_HIST 22
 
-template <int CHUNK> struct FeLayout {
-    // level s: 4 sub-arrays (plane*2 + phase), each SUB(s) doubles; O arrays start one double late so that
-    // index m0+1 (m0 multiple of 6) is 16-byte aligned, E arrays read from m0+12 (even).
-    static __host__ __device__ constexpr int sub(int s) { return (CHUNK >> (s + 1)) + FE_HIST + 14; }
-    static __host__ __device__ constexpr int level_off(int s) { int o = 0; for (int i = 0; i < s; i++) o += 4 * sub(i); return o; }
-    static __host__ __device__ constexpr int total(int S) { return level_off(S) + 2 * (CHUNK / 64 + 2) + 128; }
-};
-
-template <int CHUNK>
-__device__ __forceinline__ double *fe_arr(double *smem, int s, int plane, int phase)
-{
-    // every sub-array starts 16-byte aligned; the odd-phase (O) arrays keep their samples one slot further on
-    // (sample j at index FE_HIST + 1 + j) so that the vector reads of hb45_block start on an even index
-    return smem + FeLayout<CHUNK>::level_off(s) + (plane * 2 + phase) * FeLayout<CHUNK>::sub(s);
-}
-
-// R consecutive outputs m0..m0+R-1 of one half-band stage from the polyphase arrays of its input level.
-__device__ __forceinline__ void hb45_block(const double *__restrict__ O, const double *__restrict__ E, int m0,
-                                           double (&y)[FE_R])
-{
-    // O, E: 16-byte aligned sub-array bases; m0 is a multiple of FE_R (even).  Odd-phase sample j sits at
-    // O[FE_HIST + 1 + j], even-phase sample j at E[FE_HIST + j].
-    double o[FE_R + 22];
-    double e[FE_R];
-    const double2 *po = reinterpret_cast<const double2 *>(__builtin_assume_aligned(O, 16)) + (m0 / 2 + 1);   // O[m0 + 2 ...]
-#pragma unroll
-    for (int j = 0; j < (FE_R + 22) / 2; j++) { const double2 v = po[j]; o[2 * j] = v.x; o[2 * j + 1] = v.y; }
-    const double2 *pe = reinterpret_cast<const double2 *>(__builtin_assume_aligned(E, 16)) + (m0 / 2 + 6);   // E[m0 + 12 ...]
-#pragma unroll
-    for (int j = 0; j < FE_R / 2; j++) { const double2 v = pe[j]; e[2 * j] = v.x; e[2 * j + 1] = v.y; }
-#pragma unroll
-    for (int r = 0; r < FE_R; r++) {
-        // samples[k] = o[r+21-k]; pair k with 21-k, in the reference's order k = 0..10, then the centre tap
-        double acc = (o[r + 21] + o[r]) * HB_C0;
-        acc = fma(o[r + 20] + o[r + 1], HB_C1, acc);
-        acc = fma(o[r + 19] + o[r + 2], HB_C2, acc);
-        acc = fma(o[r + 18] + o[r + 3], HB_C3, acc);
-        acc = fma(o[r + 17] + o[r + 4], HB_C4, acc);
-        acc = fma(o[r + 16] + o[r + 5], HB_C5, acc);
-        acc = fma(o[r + 15] + o[r + 6], HB_C6, acc);
-        acc = fma(o[r + 14] + o[r + 7], HB_C7, acc);
-        acc = fma(o[r + 13] + o[r + 8], HB_C8, acc);
-        acc = fma(o[r + 12] + o[r + 9], HB_C9, acc);
-        acc = fma(o[r + 11] + o[r + 10], HB_C10, acc);
-        y[r] = fma(e[r], HB_C11, acc);
-    }
-}
-
-template <int S, int CHUNK>
-__global__ __launch_bounds__(FE_THREADS) void k_frontend(FrontArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    using LY = FeLayout<CHUNK>;
-    const int rx = blockIdx.y, t = threadIdx.x;
-    const long long g_lo = a.g_lo0 + (long long)blockIdx.x * a.span_len;
-    if (g_lo >= a.g_end) return;
-    const long long g_hi = (g_lo + a.span_len < a.g_end) ? g_lo + a.span_len : a.g_end;
-    constexpr int W = 44 << S;
-    double2 *sbase = reinterpret_cast<double2 *>(smem + LY::level_off(S));
-    double2 *sC = sbase + (CHUNK / 64 + 2);
-
-    for (int i = t; i < LY::level_off(S); i += FE_THREADS) smem[i] = 0.0;
-    const int mix = a.mt.mix_on[rx];
-    if (t < 64) sC[t] = a.mt.tabC[rx * 64 + t];
-    const double2 *histp = a.hist + (long long)rx * a.H;
-    double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
-
-    long long pos = g_lo - W;
-    while (pos < g_hi) {
-        const bool emit = pos >= g_lo;
-        const long long lim = emit ? g_hi : g_lo;
-        const int c = (lim - pos < CHUNK) ? (int)(lim - pos) : CHUNK;      // multiple of 2^S
-        const long long k0 = pos - a.N0;                                    // block-relative index of the chunk start
-        const long long jb = k0 >> 6;
-        __syncthreads();                                                    // previous chunk done with sbase / arrays
-        if (mix && t < c / 64 + 2) {
-            long long j = jb + t;
-            if (j >= 0) sbase[t] = mix_base(a.mt, rx, j);
-        }
-        __syncthreads();
-        // ---- load + mix into level 0 ----
-        {
-            double *E0 = fe_arr<CHUNK>(smem, 0, 0, 0), *O0 = fe_arr<CHUNK>(smem, 0, 0, 1);
-            double *E1 = fe_arr<CHUNK>(smem, 0, 1, 0), *O1 = fe_arr<CHUNK>(smem, 0, 1, 1);
-            for (int i = t; i < c; i += FE_THREADS) {
-                const long long k = k0 + i;
-                double2 v;
-                if (k >= 0) {
-                    v = a.x[k];
-                    if (mix) v = cmul(v, cmul(sbase[(int)((k >> 6) - jb)], sC[(int)(k & 63)]));
-                } else {
-                    const long long hi = k + a.H;
-                    v = hi >= 0 ? histp[hi] : make_double2(0.0, 0.0);
-                }
-                const int idx = FE_HIST + (i >> 1) + (i & 1);           // odd phase: one slot further on
-                double *d0 = (i & 1) ? O0 : E0, *d1 = (i & 1) ? O1 : E1;
-                d0[idx] = v.x; d1[idx] = v.y;
-            }
-        }
-        __syncthreads();
-        // ---- S half-band stages ----
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-            const int n_out = c >> (s + 1);
-            const int ipp = (n_out + FE_R - 1) / FE_R;                      // work items per plane
-            for (int w = t; w < 2 * ipp; w += FE_THREADS) {
-                const int plane = w >= ipp;
-                const int q = plane ? w - ipp : w;
-                const int m0 = q * FE_R;
-                double y[FE_R];
-                hb45_block(fe_arr<CHUNK>(smem, s, plane, 1), fe_arr<CHUNK>(smem, s, plane, 0), m0, y);
-                const bool whole = m0 + FE_R <= n_out;
-                if (s + 1 < S) {
-                    // m0 is even: outputs r = 0, 2, 4 are even-phase samples m0/2 + r/2 of the next level, r = 1, 3, 5 odd-phase
-                    double *En = fe_arr<CHUNK>(smem, s + 1, plane, 0) + FE_HIST + (m0 >> 1);
-                    double *On = fe_arr<CHUNK>(smem, s + 1, plane, 1) + FE_HIST + 1 + (m0 >> 1);
-                    // (a partial last item writes a few values past the valid range: they land in the arrays' padding)
-                    En[0] = y[0]; On[0] = y[1]; En[1] = y[2]; On[1] = y[3]; En[2] = y[4]; On[2] = y[5];
-                } else if (emit) {
-                    double *op = (plane ? out1 : out0) + ((pos >> S) - a.J0) + m0;
-                    if (whole) {
-#pragma unroll
-                        for (int r = 0; r < FE_R; r++) op[r] = y[r];
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < FE_R; r++)
-                            if (m0 + r < n_out) op[r] = y[r];
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        // ---- carry the last 22 entries of every polyphase array to its front ----
-        {
-            double keep[2];
-            int cnt = 0;
-            for (int w = t; w < S * 4 * FE_HIST; w += FE_THREADS, cnt++) {
-                const int s = w / (4 * FE_HIST), rem = w % (4 * FE_HIST);
-                const int sub = rem / FE_HIST, i = rem % FE_HIST;
-                keep[cnt] = fe_arr<CHUNK>(smem, s, sub >> 1, sub & 1)[(c >> (s + 1)) + (sub & 1) + i];
-            }
-            __syncthreads();
-            cnt = 0;
-            for (int w = t; w < S * 4 * FE_HIST; w += FE_THREADS, cnt++) {
-                const int s = w / (4 * FE_HIST), rem = w % (4 * FE_HIST);
-                const int sub = rem / FE_HIST, i = rem % FE_HIST;
-                fe_arr<CHUNK>(smem, s, sub >> 1, sub & 1)[(sub & 1) + i] = keep[cnt];
-            }
-        }
-        pos += c;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Front end, wave-independent form (the one the engine launches).  Same arithmetic and LDS polyphase layout
-// as k_frontend above, but ONE WAVE owns a receiver x span and walks it in chunks of 384 samples (6 per
-// lane) with all its levels in its own 16 KiB of LDS: no workgroup barrier ever waits for another wave,
-// so a SIMD always has a runnable wave.  The deeper (smaller) stages use fewer outputs per lane,
+// Front end kernel: ONE WAVE owns a receiver x span and walks it in chunks of 384 samples (6 per lane)
+// with all its levels in its own 16 KiB of LDS: no workgroup barrier ever waits for another wave, so a
+// SIMD always has a runnable wave.  (A 256-lane workgroup form with barriers between the stages came first
+// and was 2.5x slower.)  The deeper (smaller) stages use fewer outputs per lane,
 // R = 6, 3, 2, 1, 1, so that the 2 x 32 lanes (plane x item) stay busy; an idle lane costs a wave as much as
 // a busy one.
 // ------------------------------------------------------------------------------------------------

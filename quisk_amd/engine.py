@@ -78,6 +78,8 @@ def lib():
     L.qk_reset_stats.argtypes = [vp]
     L.qk_export_audio_device.argtypes = [vp, vp, C.c_size_t]
     L.qk_debug_tap.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    L.qk_debug_agc_passes.argtypes = [vp, C.c_int]
+    L.qk_debug_agc_passes.restype = C.c_longlong
     L.quisk_cCplxSampleFilter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip]
     L.quisk_ccfFilter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip]
     _lib = L

@@ -102,6 +102,55 @@ def test_dgt_bandwidth_change_moves_the_receiver_between_chains():
     pr2.check()
 
 
+def _bursty_iq(n, fs, tunes, seed):
+    """Keyed carriers: every receiver's tone is switched on and off at random with levels between 2^16 and 2^30, plus
+    isolated impulses: the AGC sees clip starts, ramps that are cut short by new maxima, ramps that end, window
+    boundaries with changing targets, all at arbitrary positions in its 64-sample tiles."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 2.0 ** 15
+    for f in tunes:
+        env = np.zeros(n)
+        pos = 0
+        while pos < n:
+            length = int(rng.integers(fs // 400, fs // 20))
+            if rng.random() < 0.6:
+                env[pos:pos + length] = 2.0 ** rng.uniform(16, 30)
+            pos += length
+        x += env * np.exp(2j * np.pi * ((f + 1000) / fs) * t)
+    for k in rng.integers(0, n, 12):
+        x[k] += 2.0 ** 30
+    return np.round(x.real) + 1j * np.round(x.imag)
+
+
+@pytest.mark.parametrize("agc_gain,playback,sizes", [
+    (80.0, 48000, [19200] * 10),
+    (5000.0, 48000, [4800, 19201, 7, 19200, 33333, 960, 19199, 19200, 19200]),
+    (1.0e5, 96000, [19200] * 8),
+    (20.0, 192000, [9600, 9601, 19200, 5, 19200, 19200]),
+])
+def test_agc_under_keyed_signals(agc_gain, playback, sizes):
+    """The AGC kernel (runner / walker / fetcher waves, restarts in the middle of tiles) bit for bit against the
+    oracle's process_agc on signals that keep it switching between its two states.  End to end the bound is loose on
+    purpose: what is asserted is the exactness of the AGC on identical input and the 1e-9 in front of it."""
+    fs = 192000
+    tunes, modes = [30000, -41000], [3, 4]
+    x = _bursty_iq(sum(sizes), fs, tunes, 4242 + int(agc_gain))
+    eng = Engine(fs, n_receivers=2, playback_rate=playback, max_block=max(sizes))
+    pr = PairRunner(eng, modes, tunes, agc_gain=agc_gain)
+    pos = 0
+    for n in sizes:
+        pr.step(x[pos:pos + n])
+        pos += n
+    passes = [eng.L.qk_debug_agc_passes(eng.h, r) for r in range(2)]
+    pr.close()
+    pr.check(final_tol=1.0)
+    tiles = sum(-(-(n * playback // fs) // 64) for n in sizes)
+    if agc_gain >= 5000:
+        assert max(passes) > tiles      # events did occur: more speculation passes than tiles
+    print("agc passes", passes, "tiles", tiles)
+
+
 @pytest.mark.parametrize("playback", [96000, 192000])
 def test_playback_interpolation(playback):
     """Interpolation to a 96 / 192 ksps play rate (quisk.c:2535-2553); the AGC then runs at that rate."""
