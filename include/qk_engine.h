@@ -70,9 +70,13 @@ int qk_set_agc_release_time(qk_engine *e, double seconds);
  * order.  qk_set_dc_remove: dc_remove_bw of DCremove (sound.c:165-230; set_sparams, sound.c:1253-1262): 0 = off (the
  * engine's default; Quisk's configuration default is 100), 1 = subtract the average of two-second stretches, > 1 = one-pole
  * DC blocker of that bandwidth in Hz.  qk_set_invert_spectrum: invert_spectrum (quisk.c:4174-4182, applied at
- * quisk.c:2315-2320): conjugate every sample.  The noise blanker (quisk.c:615-720) is not built. */
+ * quisk.c:2315-2320): conjugate every sample. */
 int qk_set_dc_remove(qk_engine *e, int bandwidth);
 int qk_set_invert_spectrum(qk_engine *e, int on);
+/* set_noise_blanker (quisk.c:4246-4252): quisk_noise_blanker, 0 = off, 1 / 2 / 3 = pulse limit 6 / 4 / 2.5 times the running
+ * mean magnitude; NoiseBlanker (quisk.c:615-720) then runs behind the inversion (quisk.c:2322) and delays the stream by
+ * 1.5 ms.  Switching it on starts from an empty delay line. */
+int qk_set_noise_blanker(qk_engine *e, int level);
 
 /* quisk_process_samples (quisk.h:258, quisk.c:2149-2616), for all receivers at once.
  * iq: n interleaved (re, im) doubles = C99 `complex double`, in HOST memory (copied in) ... */

@@ -1040,3 +1040,54 @@ void qko_invert_spectrum(qko_cd *x, int n)
     int i;
     for (i = 0; i < n; i++) x[i] = conj(x[i]);
 }
+
+/* NoiseBlanker, quisk.c:615-720.  Every sample goes through a ring of 3 * hwindow samples (hwindow = 500 us); the
+ * magnitudes in the ring are kept in a running sum.  A sample whose magnitude exceeds limit * (sum / size) is a pulse. */
+void qko_nb_init(qko_nbstate *b) { memset(b, 0, sizeof *b); b->sample_rate = -1; }
+void qko_nb_free(qko_nbstate *b) { free(b->ring); free(b->mags); b->ring = NULL; b->mags = NULL; }
+void qko_noise_blanker(qko_nbstate *b, qko_cd *x, int n, int sample_rate, int level)
+{
+    int i, j, k;
+    double limit;
+    if (level <= 0) return;                                         /* quisk.c:631-632 */
+    if (sample_rate != b->sample_rate) {                            /* quisk.c:633-651 */
+        b->sample_rate = sample_rate;
+        b->state = b->index = b->win_index = 0;
+        b->sum = 0.0;
+        b->hwindow = (int)(sample_rate * 500.E-6 + 0.5);
+        b->size = b->hwindow * 3;
+        b->mags = (double *)realloc(b->mags, b->size * sizeof(double));
+        memset(b->mags, 0, b->size * sizeof(double));
+        b->ring = (qko_cd *)realloc(b->ring, b->size * sizeof(qko_cd));
+        memset(b->ring, 0, b->size * sizeof(qko_cd));
+    }
+    limit = level == 2 ? 4.0 : level == 3 ? 2.5 : 6.0;              /* quisk.c:652-663 */
+    for (i = 0; i < n; i++) {                                       /* quisk.c:664-718 */
+        const qko_cd newest = x[i];
+        const double mag = cabs(newest);
+        int pulse;
+        x[i] = b->ring[b->index];                                   /* the oldest sample leaves */
+        b->ring[b->index] = newest;
+        b->sum -= b->mags[b->index];
+        b->mags[b->index] = mag;
+        b->sum += mag;
+        pulse = !(mag <= b->sum / b->size * limit);
+        if (b->state == 0) {
+            if (pulse) {                                            /* ramp down into the pulse: this sample times 0, ... */
+                b->state = 1;
+                k = b->index;
+                for (j = 0; j < b->hwindow; j++) {
+                    b->ring[k--] *= (double)j / b->hwindow;
+                    if (k < 0) k = b->size - 1;
+                }
+            } else if (b->win_index) {                              /* ramp up behind the last pulse */
+                b->ring[b->index] *= (double)b->win_index / b->hwindow;
+                if (++b->win_index >= b->hwindow) b->win_index = 0;
+            }
+        } else {
+            b->ring[b->index] = 0;                                  /* zero until the pulses stop */
+            if (!pulse) { b->state = 0; b->win_index = 1; }
+        }
+        if (++b->index >= b->size) b->index = 0;
+    }
+}

@@ -142,6 +142,15 @@ typedef struct {
 void qko_dcremove_init(qko_dcstate *d);
 void qko_dcremove(qko_dcstate *d, qko_cd *x, int n, int sample_rate, int dc_remove_bw, int key_state);
 void qko_invert_spectrum(qko_cd *x, int n);
+/* NoiseBlanker (quisk.c:615-720), its function statics as a struct: a delay line of 1.5 ms whose samples are ramped down
+ * in front of a pulse (magnitude above `limit` times the running average), zeroed during it and ramped up behind it.
+ * level 1 / 2 / 3 = limit 6 / 4 / 2.5; level <= 0 leaves the samples alone (and the delay line untouched). */
+typedef struct {
+    qko_cd *ring; double *mags; double sum; int size, hwindow, state, index, win_index, sample_rate;
+} qko_nbstate;
+void qko_nb_init(qko_nbstate *b);
+void qko_nb_free(qko_nbstate *b);
+void qko_noise_blanker(qko_nbstate *b, qko_cd *x, int n, int sample_rate, int level);
 
 /* ---- batch driver used as the timed CPU baseline --------------------------------- */
 /* run nrx receivers (already configured) over the same input block; audio of receiver r is written to

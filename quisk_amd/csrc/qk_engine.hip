@@ -138,6 +138,12 @@ struct qk_engine {
     int dc_bw = 0, invert = 0;
     double dc_alpha = 0.95; int dc_alpha_bw = -1;
     long long dc_key_delay = 0, dc_count = 0;
+    // noise blanker (k_nb_*): two sets of history arrays (a block reads one and leaves the next block's history in the other)
+    int nb_level = 0, nb_hw = 0, nb_H = 0, nb_set = 0;
+    double2 *d_nb_x[2] = {nullptr, nullptr}, *d_nb_y = nullptr;
+    double *d_nb_mag[2] = {nullptr, nullptr}, *d_nb_loc = nullptr, *d_nb_segsum = nullptr, *d_nb_segbase = nullptr, *d_nb_S = nullptr;
+    unsigned char *d_nb_p[2] = {nullptr, nullptr}, *d_nb_any = nullptr;
+    unsigned long long *d_nb_words = nullptr;
     double2 *d_cond = nullptr, *d_dc_seg_end = nullptr, *d_dc_seg_in = nullptr, *d_dc_state = nullptr;   // d_dc_state: [0] recurrence, [1] sum, [2] average
     double2 *d_dc_partial = nullptr;
     // output
@@ -1162,8 +1168,31 @@ static void launch_frontend(qk_engine *e, const FrontArgs &fa, int nspans)
     hipLaunchKernelGGL((k_frontend_wave<S>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
 }
 
-// DCremove and spectrum inversion in front of everything else; returns the buffer the rest of the block reads
-static const double2 *condition_input(qk_engine *e, const double2 *x, int n)
+// NoiseBlanker (quisk.c:2322): five launches on the front end's stream
+static const double2 *noise_blanker(qk_engine *e, const double2 *x, int n)
+{
+    hipStream_t st = e->fe_stream;
+    const int s = e->nb_set, nseg = (n + NB_SEG - 1) / NB_SEG;
+    NbArgs a{};
+    a.x = x; a.n = n;
+    a.ext_x = e->d_nb_x[s]; a.ext_mag = e->d_nb_mag[s]; a.ext_p = e->d_nb_p[s];
+    a.H = e->nb_H; a.hw = e->nb_hw; a.save = 3 * e->nb_hw;
+    a.limit = e->nb_level == 2 ? 4.0 : e->nb_level == 3 ? 2.5 : 6.0;            // quisk.c:652-663
+    a.loc = e->d_nb_loc; a.segsum = e->d_nb_segsum; a.segbase = e->d_nb_segbase; a.S = e->d_nb_S;
+    a.words = e->d_nb_words; a.any = e->d_nb_any; a.y = e->d_nb_y;
+    hipLaunchKernelGGL(k_nb_mag, dim3(nseg), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_nb_chain, dim3(1), dim3(64), 0, st, a, nseg);
+    hipLaunchKernelGGL(k_nb_flags, dim3((n + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_nb_words, dim3((a.H + n + NB_SEG - 1) / NB_SEG), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_nb_apply, dim3((n + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_nb_carry, dim3((a.H + 255) / 256), dim3(256), 0, st, a, e->d_nb_x[s ^ 1], e->d_nb_mag[s ^ 1], e->d_nb_p[s ^ 1]);
+    e->nb_set = s ^ 1;
+    return e->d_nb_y;
+}
+
+// DCremove, spectrum inversion and the noise blanker, in the reference's order, in front of everything else; returns the
+// buffer the rest of the block reads
+static const double2 *dc_and_inversion(qk_engine *e, const double2 *x, int n)
 {
     if (e->dc_bw <= 0 && !e->invert) return x;
     hipStream_t st = e->fe_stream;
@@ -1201,6 +1230,13 @@ static const double2 *condition_input(qk_engine *e, const double2 *x, int n)
     }
     hipLaunchKernelGGL(k_dc_sub, dim3((n + 255) / 256), dim3(256), 0, st, x, e->d_cond, n, (const double2 *)nullptr, 1);
     return e->d_cond;
+}
+
+static const double2 *condition_input(qk_engine *e, const double2 *x, int n)
+{
+    x = dc_and_inversion(e, x, n);
+    if (e->nb_level > 0) x = noise_blanker(e, x, n);
+    return x;
 }
 
 static int process_device(qk_engine *e, const double2 *x, int n)
@@ -1425,7 +1461,8 @@ void qk_destroy(qk_engine *e)
                     (void *)e->d_bs_out, (void *)e->d_bs_X, (void *)e->d_bs_max})
         if (p) hipFree(p);
     for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
-    void *ptrs[] = {e->d_cond, e->d_dc_seg_end, e->d_dc_seg_in, e->d_dc_state, e->d_dc_partial, e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps, e->d_cls,
+    void *ptrs[] = {e->d_nb_x[0], e->d_nb_x[1], e->d_nb_mag[0], e->d_nb_mag[1], e->d_nb_p[0], e->d_nb_p[1], e->d_nb_y, e->d_nb_loc, e->d_nb_segsum,
+                    e->d_nb_segbase, e->d_nb_S, e->d_nb_words, e->d_nb_any, e->d_cond, e->d_dc_seg_end, e->d_dc_seg_in, e->d_dc_state, e->d_dc_partial, e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps, e->d_cls,
                     e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_out,
                     e->d_fft_stage, e->d_fft_Y, e->d_tw4096, e->d_tw_lo, e->d_tw_hi, e->d_window, e->d_fft_avg, e->d_band,
                     e->d_meter, e->d_graph, e->d_pix, e->d_k0};
@@ -1501,6 +1538,45 @@ int qk_set_dc_remove(qk_engine *e, int bandwidth)
     if (bandwidth < 0) return fail(QK_EINVAL, "bad DC removal bandwidth");
     SYNC_ALL(e);
     e->dc_bw = bandwidth;
+    return QK_OK;
+}
+
+int qk_set_noise_blanker(qk_engine *e, int level)
+{
+    ENGINE_ENTER(e);
+    if (level < 0) return fail(QK_EINVAL, "bad noise blanker level");
+    SYNC_ALL(e);
+    if (level > 0 && !e->d_nb_y) {
+        // hwindow_size and save_size of quisk.c:639-640; H = history carried in front of a block (>= 4 hwindow, whole segments)
+        e->nb_hw = (int)(e->cfg.sample_rate * 500.E-6 + 0.5);
+        e->nb_H = (4 * e->nb_hw + NB_SEG - 1) / NB_SEG * NB_SEG;
+        const size_t E = (size_t)e->nb_H + e->cfg.max_block, nseg = E / NB_SEG + 2;
+        for (int s = 0; s < 2; s++) {
+            HIPCHECK(hipMalloc(&e->d_nb_x[s], E * sizeof(double2)));
+            HIPCHECK(hipMalloc(&e->d_nb_mag[s], E * sizeof(double)));
+            HIPCHECK(hipMalloc(&e->d_nb_p[s], E));
+        }
+        HIPCHECK(hipMalloc(&e->d_nb_y, (size_t)e->cfg.max_block * sizeof(double2)));
+        HIPCHECK(hipMalloc(&e->d_nb_loc, (size_t)e->cfg.max_block * sizeof(double)));
+        HIPCHECK(hipMalloc(&e->d_nb_segsum, nseg * sizeof(double)));
+        HIPCHECK(hipMalloc(&e->d_nb_segbase, nseg * sizeof(double)));
+        HIPCHECK(hipMalloc(&e->d_nb_S, sizeof(double)));
+        HIPCHECK(hipMalloc(&e->d_nb_words, nseg * 16 * sizeof(unsigned long long)));
+        HIPCHECK(hipMalloc(&e->d_nb_any, nseg));
+    }
+    if (level > 0 && e->nb_level <= 0) {
+        // switched on: an empty delay line (the reference, whose ring simply stops moving while the blanker is off, would
+        // play its stale contents first)
+        const size_t E = (size_t)e->nb_H + e->cfg.max_block;
+        for (int s = 0; s < 2; s++) {
+            HIPCHECK(hipMemset(e->d_nb_x[s], 0, E * sizeof(double2)));
+            HIPCHECK(hipMemset(e->d_nb_mag[s], 0, E * sizeof(double)));
+            HIPCHECK(hipMemset(e->d_nb_p[s], 0, E));
+        }
+        HIPCHECK(hipMemset(e->d_nb_S, 0, sizeof(double)));
+        e->nb_set = 0;
+    }
+    e->nb_level = level;
     return QK_OK;
 }
 

@@ -1359,6 +1359,171 @@ __global__ void k_dc_final(const double2 *partial, int np, double2 *sum, double2
 }
 
 // ------------------------------------------------------------------------------------------------
+// Noise blanker (NoiseBlanker, quisk.c:615-720) on the full-rate stream, behind DC removal and inversion.
+// The reference pushes every sample through a ring of 3 hw samples (hw = 500 us) and edits the ring in place: a
+// sample whose magnitude exceeds limit x (running mean of the ring's magnitudes) is a PULSE; when a pulse starts the
+// hw samples before it are multiplied by a ramp j / hw (j = 0 at the pulse), samples are zeroed while pulses last,
+// and the samples behind the last pulse are multiplied by a ramp 1/hw, 2/hw ... until it reaches one or the next
+// pulse starts.  All edits of a sample happen within hw samples of its arrival, and the state of the machine in
+// front of sample t is simply pulse[t-1]; so the output, the sample that arrived 3 hw earlier, is
+//     y[i] = x[t] * M[t],  t = i - 3 hw,
+//     M[t] = 0                                   if pulse[t-1] (zeroed) or pulse[t] (a pulse starts: ramp factor 0),
+//          = (t - r - 1) / hw  [r = the nearest pulse before t, if within hw]        (the ramp up, applied first)
+//            x  prod over pulse starts q in (t, t + hw) of (q - t) / hw, in time order    (the ramps down)
+// and everything is a function of the pulse flags within hw of t: no serial walk.  The flags need the running sum
+// of the last 3 hw magnitudes: here the previous sum plus a prefix sum of mag[k] - mag[k - 3 hw] (segments of 1024
+// samples, chained like the DC blocker), not the reference's  sum -= old; sum += new  -- another rounding order, so a
+// flag could differ from the reference's only where a magnitude meets the limit to within 1e-13; the multiplications
+// are the reference's own, in its order.  Arrays carry H >= 4 hw samples of history in front of the block ("ext"
+// coordinates: the block starts at H); pulse flags are kept as bytes, as 64-sample words and as an any-flag per 1024
+// samples so that the searches skip the quiet stretches, which is nearly all of them.
+// ------------------------------------------------------------------------------------------------
+#define NB_SEG 1024
+struct NbArgs {
+    const double2 *x; int n;            // the block
+    double2 *ext_x; double *ext_mag; unsigned char *ext_p;      // [H + n]
+    int H, hw, save;                    // save = 3 hw
+    double limit;
+    double *loc;                        // [n] prefix of the magnitude differences inside a segment
+    double *segsum, *segbase;           // [nseg]
+    double *S;                          // the running sum in front of the block; behind it afterwards
+    unsigned long long *words; unsigned char *any;   // [(H + n) / 64 + 2], [(H + n) / 1024 + 2]
+    double2 *y;                         // [n]
+};
+// magnitudes, their differences against the ones leaving the ring, prefix sums inside segments of 1024
+__global__ __launch_bounds__(64) void k_nb_mag(NbArgs a)
+{
+#pragma clang fp contract(off)
+    const int seg = blockIdx.x, lane = threadIdx.x;
+    const int base = seg * NB_SEG + lane * 16;
+    double run = 0.0, pre[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int i = base + k;
+        double d = 0.0;
+        if (i < a.n) {
+            const double2 v = a.x[i];
+            const double m = hypot(v.x, v.y);
+            a.ext_x[a.H + i] = v;
+            a.ext_mag[a.H + i] = m;
+            const int o = i - a.save;               // the sample leaving the ring: in this block, or in the history
+            double mo;
+            if (o >= 0) { const double2 w = a.x[o]; mo = hypot(w.x, w.y); } else mo = a.ext_mag[a.H + o];
+            d = m - mo;
+        }
+        run += d;
+        pre[k] = run;
+    }
+    // exclusive scan of the lane totals (a serial chain of 64 adds: one wave, 1024 samples)
+    double off = 0.0, acc = 0.0;
+    for (int L = 0; L < 64; L++) {
+        if (lane == L) off = acc;
+        acc += readlane_f64(run, L);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (base + k < a.n) a.loc[base + k] = off + pre[k];
+    if (lane == 0) a.segsum[seg] = acc;
+}
+__global__ __launch_bounds__(64) void k_nb_chain(NbArgs a, int nseg)
+{
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x;
+    double run = *a.S;
+    for (int s0 = 0; s0 < nseg; s0 += 64) {
+        const int s = s0 + lane;
+        const double e = s < nseg ? a.segsum[s] : 0.0;
+        double mine = run;
+        const int cnt = nseg - s0 < 64 ? nseg - s0 : 64;
+        for (int L = 0; L < cnt; L++) {
+            if (lane == L) mine = run;
+            run += readlane_f64(e, L);
+        }
+        if (s < nseg) a.segbase[s] = mine;
+    }
+    if (lane == 0) *a.S = run;
+}
+// pulse[t] = !(mag <= sum / size * limit)   (quisk.c:674-677)
+__global__ __launch_bounds__(256) void k_nb_flags(NbArgs a)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const double sum = a.segbase[i / NB_SEG] + a.loc[i];
+    const double m = a.ext_mag[a.H + i];
+    a.ext_p[a.H + i] = !(m <= sum / a.save * a.limit);
+}
+// the flags of all H + n samples as words and per-1024 summaries (the history has moved by a ragged count: made anew)
+__global__ __launch_bounds__(256) void k_nb_words(NbArgs a)
+{
+    const int E = a.H + a.n;
+    int got = 0;
+    for (int it = 0; it < 4; it++) {
+        const int t = blockIdx.x * NB_SEG + it * 256 + threadIdx.x;
+        const int f = t < E ? a.ext_p[t] : 0;
+        const unsigned long long w = __ballot(f);
+        if ((threadIdx.x & 63) == 0) a.words[t >> 6] = w;
+        got |= f;
+    }
+    got = __syncthreads_or(got);
+    if (threadIdx.x == 0) a.any[blockIdx.x] = got != 0;
+}
+__global__ __launch_bounds__(256) void k_nb_apply(NbArgs a)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const int t = a.H + i - a.save;                 // >= hw + (rounding of H): every index below stays inside the arrays
+    double2 u = a.ext_x[t];
+    const double hw = (double)a.hw;
+    if (a.ext_p[t - 1]) {
+        u = make_double2(0.0, 0.0);                 // state 1: "zero samples until the pulses stop" (quisk.c:696)
+    } else {
+        if (a.ext_p[t]) {
+            u = make_double2(u.x * 0.0, u.y * 0.0); // a pulse starts here: first factor of its ramp, j = 0 (quisk.c:683-684)
+        } else {
+            // the ramp up behind the nearest pulse r (quisk.c:689-693): win_index = t - (r + 1), 1 .. hw - 1
+            int q = t - 1, r = -1;
+            const int lo = t - a.hw;
+            while (q >= lo) {
+                if (!a.any[q >> 10]) { q = ((q >> 10) << 10) - 1; continue; }
+                const int wi = q >> 6;
+                const unsigned long long w = a.words[wi] & (~0ull >> (63 - (q & 63)));
+                if (w) { r = (wi << 6) + 63 - __clzll((long long)w); break; }
+                q = (wi << 6) - 1;
+            }
+            if (r >= lo) { const double f = (double)(t - r - 1) / hw; u = make_double2(u.x * f, u.y * f); }
+        }
+        // the ramps down in front of every pulse that starts within hw - 1 samples (quisk.c:680-688), in time order
+        const int hi = t + a.hw - 1;
+        int q = t + 1;
+        while (q <= hi) {
+            if (!a.any[q >> 10]) { q = ((q >> 10) + 1) << 10; continue; }
+            const int wi = q >> 6;
+            const unsigned long long w = a.words[wi], prev = a.words[wi - 1];
+            unsigned long long sw = w & ~((w << 1) | (prev >> 63));        // a pulse with no pulse right before it
+            sw &= ~0ull << (q & 63);
+            while (sw) {
+                const int pos = (wi << 6) + __ffsll((long long)sw) - 1;
+                sw &= sw - 1;
+                if (pos > hi) break;
+                const double f = (double)(pos - t) / hw;
+                u = make_double2(u.x * f, u.y * f);
+            }
+            q = (wi + 1) << 6;
+        }
+    }
+    a.y[i] = u;
+}
+// the last H samples of (ext_x, ext_mag, ext_p) become the history of the twin set
+__global__ __launch_bounds__(256) void k_nb_carry(NbArgs a, double2 *nx, double *nmag, unsigned char *np)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.H) return;
+    nx[j] = a.ext_x[a.n + j]; nmag[j] = a.ext_mag[a.n + j]; np[j] = a.ext_p[a.n + j];
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stand-alone FIR over interleaved complex samples for the filter.c drop-ins (quisk_cDecimate, filter.c:180-206;
 // quisk_cCDecimate, filter.c:208-234).  x holds ntaps-1 history samples followed by the new block.
 // ------------------------------------------------------------------------------------------------

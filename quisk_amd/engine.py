@@ -62,6 +62,7 @@ def lib():
     L.qk_graph_pending.argtypes = [vp]
     L.qk_set_dc_remove.argtypes = [vp, C.c_int]
     L.qk_set_invert_spectrum.argtypes = [vp, C.c_int]
+    L.qk_set_noise_blanker.argtypes = [vp, C.c_int]
     L.qk_multirx_graph.argtypes = [vp, vp, C.c_int, vp]
     L.qk_bandscope_init.argtypes = [vp, C.c_int]
     L.qk_add_bscope_samples.argtypes = [vp, vp, C.c_int]
@@ -158,6 +159,10 @@ class Engine:
 
     def set_invert_spectrum(self, on):
         _check(self.L.qk_set_invert_spectrum(self.h, int(bool(on))))
+
+    def set_noise_blanker(self, level):
+        """set_noise_blanker (quisk.c:4246-4252): 0 off, 1 / 2 / 3 = pulse limit 6 / 4 / 2.5."""
+        _check(self.L.qk_set_noise_blanker(self.h, int(level)))
 
     def set_agc_release_time(self, seconds):
         _check(self.L.qk_set_agc_release_time(self.h, float(seconds)))

@@ -62,6 +62,11 @@ class ODcRemove(C.Structure):
                 ("dc_count", C.c_int), ("dc_key_delay", C.c_int)]
 
 
+class ONoiseBlanker(C.Structure):
+    _fields_ = [("ring", C.c_void_p), ("mags", C.c_void_p), ("sum", C.c_double), ("size", C.c_int), ("hwindow", C.c_int),
+                ("state", C.c_int), ("index", C.c_int), ("win_index", C.c_int), ("sample_rate", C.c_int)]
+
+
 class OBscope(C.Structure):
     _fields_ = [("size", C.c_int), ("count", C.c_int), ("window", c_dp), ("avg", c_dp), ("the_max", C.c_double)]
 
@@ -121,6 +126,9 @@ def oracle():
     L.qko_dcremove_init.argtypes = [P(ODcRemove)]
     L.qko_dcremove.argtypes = [P(ODcRemove), cdp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.qko_invert_spectrum.argtypes = [cdp, C.c_int]
+    L.qko_nb_init.argtypes = [P(ONoiseBlanker)]
+    L.qko_nb_free.argtypes = [P(ONoiseBlanker)]
+    L.qko_noise_blanker.argtypes = [P(ONoiseBlanker), cdp, C.c_int, C.c_int, C.c_int]
     L.qko_bscope_init.argtypes = [P(OBscope), C.c_int]
     L.qko_bscope_free.argtypes = [P(OBscope)]
     L.qko_bscope_add.argtypes = [P(OBscope), ddp]
@@ -319,18 +327,21 @@ class OracleBscope:
 
 
 class OracleConditioner:
-    """DCremove (sound.c:165-230) then spectrum inversion (quisk.c:2315-2320), as the reference applies them in front of
-    the FFT staging and the mixer."""
+    """DCremove (sound.c:165-230), spectrum inversion (quisk.c:2315-2320), NoiseBlanker (quisk.c:615-720), as the reference
+    applies them in front of the FFT staging and the mixer."""
 
-    def __init__(self, sample_rate, dc_remove_bw=0, invert=False):
+    def __init__(self, sample_rate, dc_remove_bw=0, invert=False, noise_blanker=0):
         self.L = oracle()
-        self.fs, self.bw, self.invert = sample_rate, dc_remove_bw, invert
+        self.fs, self.bw, self.invert, self.nb_level = sample_rate, dc_remove_bw, invert, noise_blanker
         self.d = ODcRemove()
         self.L.qko_dcremove_init(C.byref(self.d))
+        self.nb = ONoiseBlanker()
+        self.L.qko_nb_init(C.byref(self.nb))
 
     def __call__(self, x):
         y = np.array(x, dtype=np.complex128, copy=True)
         self.L.qko_dcremove(C.byref(self.d), y, len(y), self.fs, self.bw, 0)
         if self.invert:
             self.L.qko_invert_spectrum(y, len(y))
+        self.L.qko_noise_blanker(C.byref(self.nb), y, len(y), self.fs, self.nb_level)      # quisk.c:2322
         return y

@@ -115,3 +115,35 @@ def test_graph_release_scaling():
     assert np.argmax(row) == N // 2 + k
     assert abs(row[N // 2 + k] - 20 * np.log10(0.5)) < 1e-6
     g.close()
+
+
+def test_noise_blanker_oracle_properties():
+    """qko_noise_blanker (NoiseBlanker, quisk.c:615-720): a delay of 3 x 500 us on quiet input; a spike and the half window
+    in front of it are ramped to zero; splitting the input into blocks changes nothing."""
+    L = B.oracle()
+    fs, hw = 192000, 96
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(20000) + 1j * rng.standard_normal(20000)) * 1000.0
+    x[9000] += 1.0e7
+    def run(sizes):
+        st = B.ONoiseBlanker(); L.qko_nb_init(C.byref(st))
+        out, pos = [], 0
+        for n in sizes:
+            y = x[pos:pos + n].copy(); pos += n
+            L.qko_noise_blanker(C.byref(st), y, len(y), fs, 1)
+            out.append(y)
+        L.qko_nb_free(C.byref(st))
+        return np.concatenate(out)
+    y = run([20000])
+    d = 3 * hw
+    assert np.array_equal(y[2000:9000 - hw + d], x[2000 - d:9000 - hw])          # plain delay away from the spike
+    assert y[9000 + d] == 0 and y[9001 + d] == 0                                   # the spike and the sample behind it
+    ramp = np.abs(y[9000 - hw + 1 + d:9000 + d]) / np.abs(x[9000 - hw + 1:9000])
+    assert np.allclose(ramp, np.arange(hw - 1, 0, -1) / hw)                        # ramp down into it
+    up = np.abs(y[9002 + d:9002 + d + hw - 1]) / np.abs(x[9002:9002 + hw - 1])
+    assert np.allclose(up, np.arange(1, hw) / hw)                                  # ramp up behind it
+    assert np.array_equal(run([7, 4096, 1, 5000, 10896]), y)
+    off = x.copy()
+    st = B.ONoiseBlanker(); L.qko_nb_init(C.byref(st))
+    L.qko_noise_blanker(C.byref(st), off, len(off), fs, 0)
+    assert np.array_equal(off, x)                                                  # level 0: untouched
