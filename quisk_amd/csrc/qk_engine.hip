@@ -36,7 +36,8 @@ constexpr int DEFAULT_TAP_CAP = 1024;
 constexpr int EV_POOL = 2048;
 
 enum StageKind { ST_FIR, ST_INTERP, ST_HBINT, ST_RESAMP, ST_RXF, ST_FMDISC, ST_IIR, ST_FRAC };
-enum ChainClass { CL_SSB = 0, CL_CW, CL_AM, CL_FM, CL_DGTW, CL_COUNT };    // CL_DGTW: DGT-U/L filtered at the decimated rate
+enum ChainClass { CL_SSB = 0, CL_CW, CL_AM, CL_FM, CL_DGTW, CL_DGTIQ, CL_COUNT };    // CL_DGTW: DGT-U/L filtered at the decimated rate;
+                                                                                     // CL_DGTIQ: complex (stereo) audio
 
 struct Stream {
     double *d = nullptr;
@@ -245,6 +246,7 @@ int class_of_mode(int mode, int bandwidth)
     case QK_AM: return CL_AM;
     case QK_FM: case QK_DGT_FM: return CL_FM;
     case QK_LSB: case QK_USB: case QK_IMD: return CL_SSB;
+    case QK_DGT_IQ: return CL_DGTIQ;
     default: return -1;
     }
 }
@@ -430,6 +432,9 @@ static int build_class(qk_engine *e, int cl)
     case CL_DGTW:   // quisk.c:1929-1939, 1955-1965
         rxf(0, 1);
         break;
+    case CL_DGTIQ:  // quisk.c:1974-1986: dRxFilterOut on the complex stream (none at 19 kHz and above), no detector
+        rxf(2, 2);
+        break;
     case CL_FM: {   // quisk.c:1887-1921
         rxf(2, 2);
         b.need_hist(b.cur, 1);
@@ -447,7 +452,7 @@ static int build_class(qk_engine *e, int cl)
     // tail: fractional decimator when the decimated rate is not 48000 (quisk.c:2528-2532) ...
     if (e->decim_srate != 48000) {
         b.need_hist(b.cur, 3);
-        Stage &s = b.add(ST_FRAC, 1, b.cur_cap + 2);
+        Stage &s = b.add(ST_FRAC, cl == CL_DGTIQ ? 2 : 1, b.cur_cap + 2);
         s.timer = T_B;
         c.frac_cap = b.cur_cap + 8;
         HIPCHECK(hipMalloc(&c.d_frac_idx, sizeof(int) * c.frac_cap));
@@ -460,7 +465,7 @@ static int build_class(qk_engine *e, int cl)
         c.frac_dindex = 1.0;                                         // dindex = 1 (quisk.c:575)
     }
     // ... then interpolation to the play rate (quisk.c:2535-2553); mono, so one plane carries both channels
-    for (int r = e->cfg.playback_rate / 48000; r > 1; r /= 2) b.hbint(1, T_B);
+    for (int r = e->cfg.playback_rate / 48000; r > 1; r /= 2) b.hbint(cl == CL_DGTIQ ? 2 : 1, T_B);
     c.play = b.cur;
     b.need_hist(b.cur, e->cfg.playback_rate * 15 / 1000);       // AGC_DELAY, quisk.c:30, 2036
     // the class input is the front chain's output stream
@@ -1139,7 +1144,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             if (n_out > 0) {
                 FracArgs a{in.view(), out.view(), c.d_frac_idx, c.d_frac_pos, n_out, d_list};
                 Timer tm(e, st.timer);
-                hipLaunchKernelGGL(k_fracdecim, grid1(n_out, 1, nlist), dim3(256), 0, e->stream, a);
+                hipLaunchKernelGGL(k_fracdecim, grid1(n_out, out.planes, nlist), dim3(256), 0, e->stream, a);
             }
             break;
         }
@@ -1359,6 +1364,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             const bool on = !c.members.empty() && c.n_out > 0;
             if (c.built) a.in_c[cl] = c.streams[c.play].view();
             a.n_c[cl] = on ? c.n_out : 0;
+            a.cpx_c[cl] = cl == CL_DGTIQ;
             m_max = std::max(m_max, a.n_c[cl]);
         }
         if (m_max > 0) {
@@ -1403,7 +1409,9 @@ static int process_device(qk_engine *e, const double2 *x, int n)
                 // delay ring (quisk.c:2033-2050): the ring (= the play stream's history) stays zero.
                 for (int r : c.members) {
                     if (e->agc_started[r]) continue;
-                    hipMemsetAsync(c.play_alt + (long long)r * play.rx_stride(), 0, sizeof(double) * play.hist, e->stream);
+                    for (int pl = 0; pl < play.planes; pl++)
+                        hipMemsetAsync(c.play_alt + (long long)r * play.rx_stride() + (long long)pl * (play.hist + play.cap), 0,
+                                       sizeof(double) * play.hist, e->stream);
                     e->agc_started[r] = 1;
                 }
             }
@@ -1496,6 +1504,14 @@ int qk_set_tune(qk_engine *e, int rx, int tune_hz)
     return upload_tune(e, rx);
 }
 
+// the tap count the band-pass kernel sees: DGT-IQ is not filtered at 19 kHz and above (quisk.c:1976); N == 0 passes through
+static int upload_ntaps(qk_engine *e, int rx)
+{
+    const int n = (e->mode[rx] == QK_DGT_IQ && e->bandwidth[rx] >= 19000) ? 0 : e->ntaps[rx];
+    HIPCHECK(hipMemcpy(e->d_ntaps + rx, &n, sizeof(int), hipMemcpyHostToDevice));
+    return QK_OK;
+}
+
 int qk_set_mode(qk_engine *e, int rx, int mode)
 {
     ENGINE_ENTER(e); RX_CHECK(e, rx);
@@ -1505,6 +1521,7 @@ int qk_set_mode(qk_engine *e, int rx, int mode)
     SYNC_ALL(e);
     e->mode[rx] = mode;
     HIPCHECK(hipMemcpy(e->d_mode + rx, &mode, sizeof(int), hipMemcpyHostToDevice));
+    { int rcn = upload_ntaps(e, rx); if (rcn != QK_OK) return rcn; }
     if (e->cls[rx] != cl) { e->cls[rx] = cl; return upload_members(e); }
     return QK_OK;
 }
@@ -1525,8 +1542,8 @@ int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int
         }
         HIPCHECK(hipMemcpy(e->d_taps + (size_t)rx * 2 * e->tap_cap, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
     }
-    HIPCHECK(hipMemcpy(e->d_ntaps + rx, &n, sizeof(int), hipMemcpyHostToDevice));
     e->ntaps[rx] = n; e->bandwidth[rx] = bandwidth; e->start_offset[rx] = start_offset;
+    { int rcn = upload_ntaps(e, rx); if (rcn != QK_OK) return rcn; }
     const int cl = class_of_mode(e->mode[rx], bandwidth);      // DGT-U/L change chain with the bandwidth
     if (cl >= 0 && cl != e->cls[rx]) { e->cls[rx] = cl; return upload_members(e); }
     return QK_OK;

@@ -558,11 +558,11 @@ __global__ __launch_bounds__(256) void k_fracdecim(FracArgs a)
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= a.n_out) return;
     const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
-    const double *__restrict__ p = sv_ptr(a.in, rx, 0) + a.idx[m];
+    const double *__restrict__ p = sv_ptr(a.in, rx, blockIdx.y) + a.idx[m];
     const double d = a.pos[m];
     const double c0 = p[-3], c1 = p[-2], c2 = p[-1], c3 = p[0];
     const double xm0 = d - 0, xm1 = d - 1, xm2 = d - 2, xm3 = d - 3;
-    sv_ptr(a.out, rx, 0)[m] = (xm1 * xm2 * xm3 * c0 / -6.0 + xm0 * xm2 * xm3 * c1 / 2.0 +
+    sv_ptr(a.out, rx, blockIdx.y)[m] = (xm1 * xm2 * xm3 * c0 / -6.0 + xm0 * xm2 * xm3 * c1 / 2.0 +
                                xm0 * xm1 * xm3 * c2 / -2.0 + xm0 * xm1 * xm2 * c3 / 6.0);
 }
 
@@ -744,6 +744,7 @@ struct AgcArgs {
     // play rate, hist >= buf_size), n_c[c] new samples this block (0: nothing to do)
     StreamView in_c[QK_AGC_CLASSES];
     int n_c[QK_AGC_CLASSES];
+    int cpx_c[QK_AGC_CLASSES];  // the class's play stream is complex (DGT-IQ): is_cpx of process_agc, magnitudes by cabs
     const int *cls;            // [rx] chain class
     double *gains;             // [rx][cap]
     int gain_stride, buf_size, n_rx;
@@ -756,6 +757,31 @@ struct AgcArgs {
     const int *started;        // [rx] 0 until the receiver's first call: the reference then only initialises
                                // and returns the block untouched (quisk.c:2033-2050)
 };
+
+// cabs for the complex AGC.  The reference's cabs is the C library's hypot; the oracle runs against glibc 2.35, whose
+// hypot (C. F. Borges, "An improved algorithm for hypot(a,b)", 2019; the variant without fused multiply-add) is
+// restated here operation for operation, so that the magnitudes, and with them every AGC decision, are the
+// oracle's bit for bit (2 x 10^7 random and integer-valued pairs checked against the library on the host).  No
+// scaling branch: the AGC's magnitudes stay far from the thresholds (2^511, 2^-459) where the library rescales.
+__device__ __forceinline__ double cabs_cr(double x, double y)
+{
+#pragma clang fp contract(off)
+    double ax = fabs(x), ay = fabs(y);
+    if (ax < ay) { const double t = ax; ax = ay; ay = t; }
+    if (ay <= ax * 0x1p-54) return ax + ay;
+    double h = sqrt(ax * ax + ay * ay), t1, t2;
+    if (h <= 2.0 * ay) {
+        const double delta = h - ay;
+        t1 = ax * (2.0 * delta - ax);
+        t2 = (delta - 2.0 * (ax - ay)) * delta;
+    } else {
+        const double delta = h - ax;
+        t1 = 2.0 * delta * (ax - 2.0 * ay);
+        t2 = (4.0 * delta - ay) * ay + delta * delta;
+    }
+    h -= (t1 + t2) / (2.0 * h);
+    return h;
+}
 
 // One sample of the reference's state machine, verbatim (quisk.c:2076-2131).
 struct AgcConst { double rel, tr, keep, ceil_, bs; int buf_size; bool fm; };
@@ -1154,9 +1180,14 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
         // ---------------- the fetcher ----------------
         // Loads are unconditional (indices clamped to the block; lanes past the end are never `mine`).
         const int nch = (T + AGC_CHUNK - 1) / AGC_CHUNK;
+        const bool cpx = a.cpx_c[cl] != 0;          // (uniform) magnitudes of a complex stream: two planes
+        const double *__restrict__ p1 = cpx ? sv_ptr(a.in_c[cl], rx, 1) : p;
         double v[AGC_CHUNK];
 #pragma unroll
-        for (int u = 0; u < AGC_CHUNK; ++u) v[u] = p[min(u * 64 + lane, last)];
+        for (int u = 0; u < AGC_CHUNK; ++u) {
+            const int ix = min(u * 64 + lane, last);
+            v[u] = cpx ? cabs_cr(p[ix], p1[ix]) : p[ix];
+        }
         bool alive = true;
         for (int ch = 0; ch < nch && alive; ++ch) {
             // buffer ch & 1 is free once chunk ch-2 is walked
@@ -1171,7 +1202,10 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
             if (lane == 0) poke(&fetched, ch + 1);
             if (ch + 1 < nch) {                     // in flight while the walker works through chunk ch
 #pragma unroll
-                for (int u = 0; u < AGC_CHUNK; ++u) v[u] = p[min(((ch + 1) * AGC_CHUNK + u) * 64 + lane, last)];
+                for (int u = 0; u < AGC_CHUNK; ++u) {
+                    const int ix = min(((ch + 1) * AGC_CHUNK + u) * 64 + lane, last);
+                    v[u] = cpx ? cabs_cr(p[ix], p1[ix]) : p[ix];
+                }
             }
         }
     }
@@ -1184,6 +1218,20 @@ __global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
     const int cl = a.cls[rx];
     if (i >= a.n_c[cl]) return;
     const double *p = sv_ptr(a.in_c[cl], rx, 0) + i;
+    if (a.cpx_c[cl]) {                      // stereo: Re = left, Im = right (quisk.c:2556-2558), gain on the complex sample
+        const double *q = sv_ptr(a.in_c[cl], rx, 1) + i;
+        double2 d;
+        if (!a.started[rx]) {
+            d = make_double2(p[0], q[0]);
+        } else {
+            const double g = a.gains[(long long)rx * a.gain_stride + i];
+            d = make_double2(p[-a.buf_size] * g, q[-a.buf_size] * g);
+            const double m = cabs_cr(d.x, d.y);
+            if (m > QK_CLIP32) d = make_double2(d.x / m, d.y / m);
+        }
+        a.out[(long long)rx * a.out_stride + i] = d;
+        return;
+    }
     double d;
     if (!a.started[rx]) {
         d = p[0];

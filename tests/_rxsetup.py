@@ -68,11 +68,12 @@ class AgcTwin:
         self.st = B.OAgc()
         self.L.qko_agc_init(C.byref(self.st), 0.7, 0)
         self.rate, self.gain, self.fm = playback_rate, agc_gain, int(mode in (5, 13))
+        self.cpx = int(mode == 9)       # DGT-IQ: stereo, process_agc with is_cpx (quisk.c:2556-2558)
 
-    def run(self, mono):
-        s = (mono + 1j * mono).astype(np.complex128)
+    def run(self, pre):
+        s = np.array(pre, dtype=np.complex128) if self.cpx else (pre + 1j * pre).astype(np.complex128)
         if len(s):
-            self.L.qko_agc_process(C.byref(self.st), s, len(s), 0, self.rate, self.gain, 1.0, self.fm)
+            self.L.qko_agc_process(C.byref(self.st), s, len(s), self.cpx, self.rate, self.gain, 1.0, self.fm)
         return s
 
 
@@ -92,23 +93,31 @@ class PairRunner:
         self.samples = 0
         self.peak = [0.0] * len(self.oras)
         self.pre_tol = pre_tol
+        self.stereo_seen = False
 
     def step(self, blk):
         self.eng.process(blk)
         for r, o in enumerate(self.oras):
             pre_o, fin_o = o.process_parts(blk)
             fin_g = self.eng.audio(r)
-            pre_g = self.eng.tap(TAP_PLAY, r, planes=1)[0]
+            if self.modes[r] == 9:      # DGT-IQ: the play stream is complex
+                pg = self.eng.tap(TAP_PLAY, r, planes=2)
+                pre_g = pg[0] + 1j * pg[1]
+            else:
+                pre_g = self.eng.tap(TAP_PLAY, r, planes=1)[0]
             assert len(fin_g) == len(fin_o) == len(pre_g), (len(fin_g), len(fin_o), len(pre_g))
             if not len(fin_o):
                 continue
             self.samples += len(fin_o)
             # errors are taken relative to the receiver's running audio peak, so that an almost silent
             # start-up block is not judged against its own tiny amplitude
-            self.peak[r] = max(self.peak[r], float(np.max(np.abs(pre_o.real))))
+            ref = pre_o if self.modes[r] == 9 else pre_o.real
+            self.peak[r] = max(self.peak[r], float(np.max(np.abs(ref))))
             scale = self.peak[r] if self.peak[r] > 0 else 1.0
-            self.pre_err = max(self.pre_err, float(np.max(np.abs(pre_g - pre_o.real))) / scale)
+            self.pre_err = max(self.pre_err, float(np.max(np.abs(pre_g - ref))) / scale)
             twin = self.twins[r].run(pre_g)
+            if self.modes[r] == 9 and np.any(fin_g.real != fin_g.imag):
+                self.stereo_seen = True
             if not np.array_equal(twin.view(np.float64), fin_g.view(np.float64)):
                 self.agc_exact = False
             fscale = max(float(np.max(np.abs(fin_o))), 1.0)

@@ -80,6 +80,18 @@ def test_digital_modes(mode, bw):
     pr.check()
 
 
+@pytest.mark.parametrize("bw,playback,fs", [(6000, 48000, 192000), (20000, 48000, 192000), (6000, 96000, 192000),
+                                             (3000, 48000, 250000)])
+def test_dgt_iq_stereo(bw, playback, fs):
+    """DGT-IQ (quisk.c:1974-1986): the filtered complex stream itself is the audio, left = Re, right = Im; no filter at
+    19 kHz and above; the AGC works on complex magnitudes (is_cpx, quisk.c:2556-2558); at 250 ksps the resampler and the
+    fractional decimator run on both planes."""
+    sizes = [9600, 4801, 9599, 9600, 9600] if fs == 192000 else [12500, 6001, 12500, 12500]
+    pr = _stream(fs, [9, 3], [-18000, 25000], sizes, 57, playback=playback, bws=[bw, 2800])
+    pr.check()
+    assert pr.stereo_seen
+
+
 def test_dgt_bandwidth_change_moves_the_receiver_between_chains():
     """set_filters with a bandwidth across DGT_NARROW_FREQ switches a DGT-U receiver between the two chains; a USB
     receiver beside it is not disturbed."""
