@@ -132,7 +132,7 @@ struct qk_engine {
     // per receiver
     double *d_taps = nullptr; int *d_ntaps = nullptr, *d_mode = nullptr, *d_cls = nullptr; double *d_release_gain = nullptr;
     std::vector<int> ntaps, bandwidth, start_offset;
-    AgcState *d_agc = nullptr; double *d_gains = nullptr; int gain_stride = 0;
+    AgcState *d_agc = nullptr; double *d_gains = nullptr, *d_agc_mag = nullptr; int gain_stride = 0;   // d_agc_mag: [rx][gain_stride] cabs of complex play streams
     int *d_agc_started = nullptr; std::vector<char> agc_started;    // per receiver: has process_agc run once?
     double agc_release_time = 1.0;
     // input conditioning (DCremove, sound.c:165-230; spectrum inversion, quisk.c:2315-2320)
@@ -617,6 +617,7 @@ static int init_receivers(qk_engine *e)
     HIPCHECK(hipMalloc(&e->d_out, nrx * e->out_stride * sizeof(double2)));
     HIPCHECK(hipMemset(e->d_out, 0, nrx * e->out_stride * sizeof(double2)));
     HIPCHECK(hipMalloc(&e->d_gains, nrx * e->gain_stride * sizeof(double)));
+    HIPCHECK(hipMalloc(&e->d_agc_mag, nrx * e->gain_stride * sizeof(double)));
     // class chains are built when a receiver first enters the class (all receivers start as USB).  Their
     // input is the front chain's last stream: give it the largest history any class reads back
     // (the receive band-pass of the FM class reads it directly; the others put a 98-tap FIR first).
@@ -1359,12 +1360,15 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         const int rate = e->cfg.playback_rate;
         AgcArgs a{};
         int m_max = 0;
+        bool any_cpx = false;
         for (int cl = 0; cl < CL_COUNT; cl++) {
             Chain &c = e->cls_chain[cl];
             const bool on = !c.members.empty() && c.n_out > 0;
             if (c.built) a.in_c[cl] = c.streams[c.play].view();
             a.n_c[cl] = on ? c.n_out : 0;
             a.cpx_c[cl] = cl == CL_DGTIQ;
+            a.mag_c[cl] = a.in_c[cl];
+            if (a.cpx_c[cl]) { a.mag_c[cl] = StreamView{e->d_agc_mag, e->gain_stride, e->gain_stride, 0}; any_cpx = any_cpx || on; }
             m_max = std::max(m_max, a.n_c[cl]);
         }
         if (m_max > 0) {
@@ -1376,6 +1380,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             a.out = e->d_out; a.out_stride = (long long)e->out_stride;
             a.started = e->d_agc_started;
             Timer tm(e, QK_KT_AGC, e->agc_stream);
+            if (any_cpx) hipLaunchKernelGGL(k_agc_cabs, grid1(m_max, 1, e->nrx), dim3(256), 0, e->agc_stream, a);
             hipLaunchKernelGGL(k_agc_gain, dim3(e->nrx), dim3(192), 0, e->agc_stream, a);
             hipLaunchKernelGGL(k_agc_apply, grid1(m_max, 1, e->nrx), dim3(256), 0, e->agc_stream, a);
             for (int cl = 0; cl < CL_COUNT; cl++) {
@@ -1471,7 +1476,7 @@ void qk_destroy(qk_engine *e)
     for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
     void *ptrs[] = {e->d_nb_x[0], e->d_nb_x[1], e->d_nb_mag[0], e->d_nb_mag[1], e->d_nb_p[0], e->d_nb_p[1], e->d_nb_y, e->d_nb_loc, e->d_nb_segsum,
                     e->d_nb_segbase, e->d_nb_S, e->d_nb_words, e->d_nb_any, e->d_cond, e->d_dc_seg_end, e->d_dc_seg_in, e->d_dc_state, e->d_dc_partial, e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps, e->d_cls,
-                    e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_out,
+                    e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_agc_mag, e->d_out,
                     e->d_fft_stage, e->d_fft_Y, e->d_tw4096, e->d_tw_lo, e->d_tw_hi, e->d_window, e->d_fft_avg, e->d_band,
                     e->d_meter, e->d_graph, e->d_pix, e->d_k0};
     for (void *p : ptrs) if (p) hipFree(p);

@@ -745,6 +745,8 @@ struct AgcArgs {
     StreamView in_c[QK_AGC_CLASSES];
     int n_c[QK_AGC_CLASSES];
     int cpx_c[QK_AGC_CLASSES];  // the class's play stream is complex (DGT-IQ): is_cpx of process_agc, magnitudes by cabs
+    StreamView mag_c[QK_AGC_CLASSES];   // what k_agc_gain takes magnitudes of: in_c, or for a complex class the cabs that
+                                        // k_agc_cabs has left in a plane of its own (the gain kernel stays free of that code)
     const int *cls;            // [rx] chain class
     double *gains;             // [rx][cap]
     int gain_stride, buf_size, n_rx;
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
     __syncthreads();
     __builtin_amdgcn_s_setprio(3);      // latency-bound waves among the front end's throughput-bound ones: issue first
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const double *__restrict__ p = sv_ptr(a.in_c[cl], rx, 0);
+    const double *__restrict__ p = sv_ptr(a.mag_c[cl], rx, 0);
     double *__restrict__ g = a.gains + (long long)rx * a.gain_stride;
     AgcState s = a.state[rx];
     AgcConst c;
@@ -1180,14 +1182,12 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
         // ---------------- the fetcher ----------------
         // Loads are unconditional (indices clamped to the block; lanes past the end are never `mine`).
         const int nch = (T + AGC_CHUNK - 1) / AGC_CHUNK;
-        const bool cpx = a.cpx_c[cl] != 0;          // (uniform) magnitudes of a complex stream: two planes
-        const double *__restrict__ p1 = cpx ? sv_ptr(a.in_c[cl], rx, 1) : p;
         double v[AGC_CHUNK];
+        auto load_chunk = [&](const int ch) {
 #pragma unroll
-        for (int u = 0; u < AGC_CHUNK; ++u) {
-            const int ix = min(u * 64 + lane, last);
-            v[u] = cpx ? cabs_cr(p[ix], p1[ix]) : p[ix];
-        }
+            for (int u = 0; u < AGC_CHUNK; ++u) v[u] = p[min((ch * AGC_CHUNK + u) * 64 + lane, last)];
+        };
+        load_chunk(0);
         bool alive = true;
         for (int ch = 0; ch < nch && alive; ++ch) {
             // buffer ch & 1 is free once chunk ch-2 is walked
@@ -1200,15 +1200,18 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
             for (int u = 0; u < AGC_CHUNK; ++u) sm[ch & 1][u * 64 + lane] = fabs(v[u]);
             AGC_LDS_WAIT();
             if (lane == 0) poke(&fetched, ch + 1);
-            if (ch + 1 < nch) {                     // in flight while the walker works through chunk ch
-#pragma unroll
-                for (int u = 0; u < AGC_CHUNK; ++u) {
-                    const int ix = min(((ch + 1) * AGC_CHUNK + u) * 64 + lane, last);
-                    v[u] = cpx ? cabs_cr(p[ix], p1[ix]) : p[ix];
-                }
-            }
+            if (ch + 1 < nch) load_chunk(ch + 1);   // in flight while the walker works through chunk ch
         }
     }
+}
+// magnitudes of the complex classes' new samples, for k_agc_gain (grid: samples, 1, receivers)
+__global__ __launch_bounds__(256) void k_agc_cabs(AgcArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int rx = blockIdx.z;
+    const int cl = a.cls[rx];
+    if (!a.cpx_c[cl] || i >= a.n_c[cl]) return;
+    sv_ptr(a.mag_c[cl], rx, 0)[i] = cabs_cr(sv_ptr(a.in_c[cl], rx, 0)[i], sv_ptr(a.in_c[cl], rx, 1)[i]);
 }
 __global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
 {
