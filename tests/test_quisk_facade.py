@@ -124,4 +124,8 @@ def test_set_filters_errors_and_multirx_and_bandscope():
     assert QS.get_overrange() == 0
     QS.set_params(clip=1)
     assert QS.get_overrange() == 1 and QS.get_overrange() == 0
+    # conditioning setters of the path reach the engine (quisk.c:4246, 4174; sound.c:1253)
+    QS.set_noise_blanker(2); QS.invert_spectrum(1); QS.set_sparams(dc_remove_bw=100)
+    QS.add_rx_samples(raw.tobytes()); assert QS.read_sound() == len(x)
+    QS.set_noise_blanker(0); QS.invert_spectrum(0); QS.set_sparams(dc_remove_bw=0)
     QS.close_sound()
