@@ -73,6 +73,14 @@ int qk_set_agc_release_time(qk_engine *e, double seconds);
  * quisk.c:2315-2320): conjugate every sample. */
 int qk_set_dc_remove(qk_engine *e, int bandwidth);
 int qk_set_invert_spectrum(qk_engine *e, int on);
+/* set_squelch (quisk.c:4348-4354): squelch_level, the FM squelch threshold in dB re full scale (-999 = never closed); an FM or
+ * DGT-FM receiver is muted, behind its AGC (quisk.c:2590-2593), while the mean magnitude of its filtered samples, taken over
+ * stretches of at least 2400 samples closed at block ends (quisk.c:1892-1893, 1911-1920), is below it.  qk_squelch_active:
+ * MeasureSquelch[bank].squelch_active of the last block (1 = muted, 0 = open, < 0 error).  set_kill_audio (quisk.c:4364-4370):
+ * replace every receiver's audio with silence (quisk.c:2585-2589).  The SSB squelch and the graph-based IsSquelch are not built. */
+int qk_set_squelch(qk_engine *e, double level_db);
+int qk_squelch_active(qk_engine *e, int rx);
+int qk_set_kill_audio(qk_engine *e, int on);
 /* set_noise_blanker (quisk.c:4246-4252): quisk_noise_blanker, 0 = off, 1 / 2 / 3 = pulse limit 6 / 4 / 2.5 times the running
  * mean magnitude; NoiseBlanker (quisk.c:615-720) then runs behind the inversion (quisk.c:2322) and delays the stream by
  * 1.5 ms.  Switching it on starts from an empty delay line. */

@@ -426,6 +426,8 @@ int qko_fracdecim(qko_fracstate *s, qko_cd *x, int n, double fdecim)
 struct qko_rx {
     int sample_rate, playback_rate, mode, tune;
     double release_gain, release_time;
+    /* FM squelch (MeasureSquelch, quisk.c:203-214; squelch_level 147) and kill_audio (quisk.c:103) */
+    double squelch_level, sq_rf_sum, sq_value; int sq_rf_count, sq_active, kill_audio;
     qko_cd tune_vec;                                     /* rxTuneVector, quisk.c:2168 */
     /* quisk_process_decimate Storage, quisk.c:1554-1574 */
     int planned_rate, d2, d3, d5;
@@ -455,6 +457,7 @@ qko_rx *qko_rx_new(int sample_rate, int playback_rate)
     rx->sample_rate = sample_rate; rx->playback_rate = playback_rate;
     rx->mode = QKO_USB; rx->tune_vec = 1;
     rx->release_gain = 80; rx->release_time = 1.0;       /* quisk.c:145-146 */
+    rx->squelch_level = -999.0;                          /* quisk.c:147 */
 #define CI(f, nm) do { h = qko_table(#nm, &n); qko_cfir_init(&rx->f, h, n); } while (0)
 #define DI(f, nm) do { h = qko_table(#nm, &n); qko_dfir_init(&rx->f, h, n); } while (0)
     CI(sdriq111, qk_h_sdriq111_114); CI(sdriq53, qk_h_sdriq53_55); CI(sdriq133, qk_h_sdriq133_136);
@@ -504,6 +507,9 @@ void qko_rx_free(qko_rx *rx)
     free(rx);
 }
 
+void qko_rx_set_squelch(qko_rx *rx, double level_db) { rx->squelch_level = level_db; }       /* set_squelch, quisk.c:4348 */
+void qko_rx_set_kill_audio(qko_rx *rx, int on) { rx->kill_audio = on; }                        /* set_kill_audio, quisk.c:4364 */
+int  qko_rx_squelch_active(const qko_rx *rx) { return rx->sq_active; }
 void qko_rx_set_tune(qko_rx *rx, int tune_hz) { rx->tune = tune_hz; }
 void qko_rx_set_mode(qko_rx *rx, int mode) { rx->mode = mode; }
 void qko_rx_set_agc(qko_rx *rx, double release_gain, double release_time)
@@ -629,6 +635,7 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
     int i, narrow;
     qko_cd c, p;
     double m, d, di;
+    rx->sq_active = 0;                                   /* quisk.c:1777 */
     switch (rx->mode) {
     case QKO_CWL: case QKO_CWU:
         rx->filter_srate = rx->decim_srate / 8;
@@ -660,6 +667,8 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
         rx->filter_srate = rx->decim_srate;
         for (i = 0; i < n; i++) {
             c = rx_bandpass_real(rx, x[i]);
+            rx->sq_rf_sum += cabs(c);                    /* quisk.c:1892-1893 */
+            rx->sq_rf_count += 1;
             p = c * conj(rx->fm_1);
             rx->fm_1 = c;
             di = rx->filter_srate * carg(p);
@@ -669,6 +678,12 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
         n = qko_ddecimate(a, n, &rx->aud24p3, 2);
         n = qko_dfilter(a, n, &rx->fmhp);
         n = qko_dinterp2hb45(a, n, &rx->dem_hb6);
+        if (rx->sq_rf_count >= 2400) {                   /* quisk.c:1911-1918: mean magnitude in dB re full scale */
+            rx->sq_value = rx->sq_rf_sum / rx->sq_rf_count / QKO_CLIP32;
+            rx->sq_value = rx->sq_value > 1.E-10 ? 20 * log10(rx->sq_value) : -200.0;
+            rx->sq_rf_sum = 0; rx->sq_rf_count = 0;
+        }
+        rx->sq_active = rx->sq_value < rx->squelch_level;                /* quisk.c:1920 */
         break;
     case QKO_DGT_U: case QKO_DGT_L:
         narrow = rx->bandwidth < 3000;                   /* DGT_NARROW_FREQ, quisk.c:35 */
@@ -740,8 +755,11 @@ int qko_rx_pre_agc(qko_rx *rx, qko_cd *x, int n)
 
 void qko_rx_agc(qko_rx *rx, qko_cd *x, int n)
 {   /* quisk.c:2556-2575 */
+    int i;
     qko_agc_process(&rx->agc, x, n, rx->mode == QKO_DGT_IQ, rx->playback_rate, rx->release_gain,
                     rx->release_time, rx->mode == QKO_FM || rx->mode == QKO_DGT_FM);
+    if (rx->kill_audio || rx->sq_active)                 /* quisk.c:2585-2593: silence behind the AGC */
+        for (i = 0; i < n; i++) x[i] = 0;
 }
 
 int qko_rx_process(qko_rx *rx, qko_cd *x, int n)

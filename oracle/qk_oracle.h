@@ -81,6 +81,9 @@ typedef struct qko_rx qko_rx;
  * at quisk.c:2161-2181, Storage[] at 1554-1574 and 1730-1747, cRxFilterOut/dRxFilterOut rings). */
 qko_rx *qko_rx_new(int sample_rate, int playback_rate);
 void qko_rx_free(qko_rx *rx);
+void qko_rx_set_squelch(qko_rx *rx, double level_db);                  /* set_squelch, quisk.c:4348 (FM squelch level, dB) */
+void qko_rx_set_kill_audio(qko_rx *rx, int on);                        /* set_kill_audio, quisk.c:4364 */
+int  qko_rx_squelch_active(const qko_rx *rx);
 void qko_rx_set_tune(qko_rx *rx, int tune_hz);                         /* set_tune, quisk.c:4323 */
 void qko_rx_set_mode(qko_rx *rx, int mode);                            /* set_rx_mode, quisk.c:4262 */
 int  qko_rx_set_filter(qko_rx *rx, const double *fi, const double *fq, int n, int bandwidth); /* set_filters, quisk.c:4192 */

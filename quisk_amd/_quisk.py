@@ -366,6 +366,16 @@ def invert_spectrum(on):
     _st().eng.set_invert_spectrum(int(on))
 
 
+def set_squelch(level):
+    """quisk.c:4348-4354: the FM squelch level."""
+    _st().eng.set_squelch(float(level))
+
+
+def set_kill_audio(on):
+    """quisk.c:4364-4370."""
+    _st().eng.set_kill_audio(int(on))
+
+
 def set_noise_blanker(level):
     """quisk.c:4246-4252."""
     _st().eng.set_noise_blanker(int(level))
@@ -376,7 +386,7 @@ def _inert(*args, **kw):
 
 
 # Entries of QuiskMethods outside the receive path: accepted and ignored.
-INERT = ("set_volume", "set_squelch", "set_ssb_squelch", "set_auto_notch", "set_kill_audio",
+INERT = ("set_volume", "set_ssb_squelch", "set_auto_notch",
          "set_split_rxtx", "set_multirx_play_method", "set_multirx_play_channel", "set_enable_bandscope",
          "add_tone", "set_spot_level", "set_imd_level", "set_key_down", "set_ctcss", "set_tx_audio", "set_record_state",
          "set_file_name", "set_sidetone", "set_transmit_mode", "set_fdx", "set_sample_bytes",

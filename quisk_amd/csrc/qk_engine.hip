@@ -132,6 +132,8 @@ struct qk_engine {
     // per receiver
     double *d_taps = nullptr; int *d_ntaps = nullptr, *d_mode = nullptr, *d_cls = nullptr; double *d_release_gain = nullptr;
     std::vector<int> ntaps, bandwidth, start_offset;
+    // FM squelch and kill_audio: d_sq_state [rx][3], d_sq_flag [2][rx] (one set per block in flight towards the AGC)
+    double squelch_level = -999.0; int kill_audio = 0; double *d_sq_state = nullptr; int *d_sq_flag = nullptr;
     AgcState *d_agc = nullptr; double *d_gains = nullptr, *d_agc_mag = nullptr; int gain_stride = 0;   // d_agc_mag: [rx][gain_stride] cabs of complex play streams
     int *d_agc_started = nullptr; std::vector<char> agc_started;    // per receiver: has process_agc run once?
     double agc_release_time = 1.0;
@@ -618,6 +620,10 @@ static int init_receivers(qk_engine *e)
     HIPCHECK(hipMemset(e->d_out, 0, nrx * e->out_stride * sizeof(double2)));
     HIPCHECK(hipMalloc(&e->d_gains, nrx * e->gain_stride * sizeof(double)));
     HIPCHECK(hipMalloc(&e->d_agc_mag, nrx * e->gain_stride * sizeof(double)));
+    HIPCHECK(hipMalloc(&e->d_sq_state, nrx * 3 * sizeof(double)));
+    HIPCHECK(hipMemset(e->d_sq_state, 0, nrx * 3 * sizeof(double)));
+    HIPCHECK(hipMalloc(&e->d_sq_flag, 2 * nrx * sizeof(int)));
+    HIPCHECK(hipMemset(e->d_sq_flag, 0, 2 * nrx * sizeof(int)));
     // class chains are built when a receiver first enters the class (all receivers start as USB).  Their
     // input is the front chain's last stream: give it the largest history any class reads back
     // (the receive band-pass of the FM class reads it directly; the others put a 98-tap FIR first).
@@ -1097,6 +1103,10 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
                 const int tqp = std::max(FT_QB, (nmax + FT_QB - 1) / FT_QB * FT_QB);
                 const dim3 grid((n_in + FT_NTH * FT_R - 1) / (FT_NTH * FT_R), 1, nlist);
                 hipLaunchKernelGGL((k_rxf_tiled<FT_NTH, FT_R>), grid, dim3(FT_NTH), sizeof(double) * (FT_NTH * FT_R + tqp), e->stream, a);
+                if (&c == &e->cls_chain[CL_FM]) {       // the FM squelch measures the filtered samples (quisk.c:1892)
+                    SquelchArgs q{out.view(), n_in, d_list, e->d_sq_state, e->d_sq_flag + (e->stats.blocks & 1) * e->nrx, e->squelch_level};
+                    hipLaunchKernelGGL(k_fm_squelch, dim3(nlist), dim3(256), 0, e->stream, q);
+                }
             }
             break;
         }
@@ -1379,6 +1389,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             a.release_gain = e->d_release_gain; a.mode = e->d_mode; a.state = e->d_agc;
             a.out = e->d_out; a.out_stride = (long long)e->out_stride;
             a.started = e->d_agc_started;
+            a.mute = e->d_sq_flag + par * e->nrx; a.kill = e->kill_audio;
             Timer tm(e, QK_KT_AGC, e->agc_stream);
             if (any_cpx) hipLaunchKernelGGL(k_agc_cabs, grid1(m_max, 1, e->nrx), dim3(256), 0, e->agc_stream, a);
             hipLaunchKernelGGL(k_agc_gain, dim3(e->nrx), dim3(192), 0, e->agc_stream, a);
@@ -1476,7 +1487,7 @@ void qk_destroy(qk_engine *e)
     for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
     void *ptrs[] = {e->d_nb_x[0], e->d_nb_x[1], e->d_nb_mag[0], e->d_nb_mag[1], e->d_nb_p[0], e->d_nb_p[1], e->d_nb_y, e->d_nb_loc, e->d_nb_segsum,
                     e->d_nb_segbase, e->d_nb_S, e->d_nb_words, e->d_nb_any, e->d_cond, e->d_dc_seg_end, e->d_dc_seg_in, e->d_dc_state, e->d_dc_partial, e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps, e->d_cls,
-                    e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_agc_mag, e->d_out,
+                    e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_agc_mag, e->d_sq_state, e->d_sq_flag, e->d_out,
                     e->d_fft_stage, e->d_fft_Y, e->d_tw4096, e->d_tw_lo, e->d_tw_hi, e->d_window, e->d_fft_avg, e->d_band,
                     e->d_meter, e->d_graph, e->d_pix, e->d_k0};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -1527,6 +1538,7 @@ int qk_set_mode(qk_engine *e, int rx, int mode)
     e->mode[rx] = mode;
     HIPCHECK(hipMemcpy(e->d_mode + rx, &mode, sizeof(int), hipMemcpyHostToDevice));
     { int rcn = upload_ntaps(e, rx); if (rcn != QK_OK) return rcn; }
+    for (int b = 0; b < 2; b++) HIPCHECK(hipMemset(e->d_sq_flag + b * e->nrx + rx, 0, sizeof(int)));     // squelch_active = 0, quisk.c:1777
     if (e->cls[rx] != cl) { e->cls[rx] = cl; return upload_members(e); }
     return QK_OK;
 }
@@ -1561,6 +1573,31 @@ int qk_set_dc_remove(qk_engine *e, int bandwidth)
     SYNC_ALL(e);
     e->dc_bw = bandwidth;
     return QK_OK;
+}
+
+int qk_set_squelch(qk_engine *e, double level_db)
+{
+    ENGINE_ENTER(e);
+    SYNC_ALL(e);
+    e->squelch_level = level_db;
+    return QK_OK;
+}
+
+int qk_set_kill_audio(qk_engine *e, int on)
+{
+    ENGINE_ENTER(e);
+    SYNC_ALL(e);
+    e->kill_audio = on != 0;
+    return QK_OK;
+}
+
+int qk_squelch_active(qk_engine *e, int rx)
+{
+    ENGINE_ENTER(e); RX_CHECK(e, rx);
+    SYNC_ALL(e);
+    int f = 0;
+    HIPCHECK(hipMemcpy(&f, e->d_sq_flag + ((e->stats.blocks + 1) & 1) * e->nrx + rx, sizeof(int), hipMemcpyDeviceToHost));
+    return f;
 }
 
 int qk_set_noise_blanker(qk_engine *e, int level)

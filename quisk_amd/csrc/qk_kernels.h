@@ -637,6 +637,37 @@ __global__ __launch_bounds__(256) void k_fm_disc(FmDiscArgs a)
     sv_ptr(a.out, rx, 0)[i] = a.fs * atan2(im, re);
 }
 
+// FM squelch (quisk.c:1892-1893, 1911-1920): the mean magnitude of the filtered samples over stretches of at least 2400
+// samples, closed at block ends as in the reference, in dB re full scale; the receiver is muted while it is below the
+// level.  One workgroup per receiver; the block's sum is a fixed-order tree (the reference adds sample by sample: the
+// sums differ in the last bits, the decision only if the level is met to 1e-13 dB).
+struct SquelchArgs { StreamView in; int n; const int *rx_list; double *state; int *flag; double level; };   // state: [rx][3] sum, count, dB
+__global__ __launch_bounds__(256) void k_fm_squelch(SquelchArgs a)
+{
+    __shared__ double red[256];
+    const int rx = a.rx_list ? a.rx_list[blockIdx.x] : blockIdx.x;
+    const double *pr = sv_ptr(a.in, rx, 0), *pi = sv_ptr(a.in, rx, 1);
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < a.n; i += 256) acc += hypot(pr[i], pi[i]);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double *st = a.state + 3 * rx;
+        double sum = st[0] + red[0], cnt = st[1] + a.n, db = st[2];
+        if (cnt >= 2400.0) {
+            db = sum / cnt / QK_CLIP32;
+            db = db > 1.E-10 ? 20 * log10(db) : -200.0;
+            sum = 0.0; cnt = 0.0;
+        }
+        st[0] = sum; st[1] = cnt; st[2] = db;
+        a.flag[rx] = db < a.level;
+    }
+}
+
 // One-pole recurrences of the demodulators, as a scan.
 //   kind 0: AM DC removal (quisk.c:1869-1871): d = m + 0.99 dc; y = d - dc; dc = d.
 //   kind 1: FM de-emphasis (quisk.c:1898-1900): y = x a0 + x1 a1 - y1 b1.
@@ -745,6 +776,8 @@ struct AgcArgs {
     StreamView in_c[QK_AGC_CLASSES];
     int n_c[QK_AGC_CLASSES];
     int cpx_c[QK_AGC_CLASSES];  // the class's play stream is complex (DGT-IQ): is_cpx of process_agc, magnitudes by cabs
+    const int *mute;            // [rx] FM squelch closed for this block (quisk.c:2590-2593); may be null
+    int kill;                   // kill_audio (quisk.c:2585-2589)
     StreamView mag_c[QK_AGC_CLASSES];   // what k_agc_gain takes magnitudes of: in_c, or for a complex class the cabs that
                                         // k_agc_cabs has left in a plane of its own (the gain kernel stays free of that code)
     const int *cls;            // [rx] chain class
@@ -1232,6 +1265,7 @@ __global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
             const double m = cabs_cr(d.x, d.y);
             if (m > QK_CLIP32) d = make_double2(d.x / m, d.y / m);
         }
+        if (a.kill || (a.mute && a.mute[rx])) d = make_double2(0.0, 0.0);
         a.out[(long long)rx * a.out_stride + i] = d;
         return;
     }
@@ -1243,6 +1277,7 @@ __global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
         const double m = fabs(d);
         if (m > QK_CLIP32) d = d / m;      // sic: the reference divides by the magnitude (quisk.c:2065)
     }
+    if (a.kill || (a.mute && a.mute[rx])) d = 0.0;      // silence behind the AGC, whose state moves on
     a.out[(long long)rx * a.out_stride + i] = make_double2(d, d);
 }
 

@@ -63,6 +63,9 @@ def lib():
     L.qk_set_dc_remove.argtypes = [vp, C.c_int]
     L.qk_set_invert_spectrum.argtypes = [vp, C.c_int]
     L.qk_set_noise_blanker.argtypes = [vp, C.c_int]
+    L.qk_set_squelch.argtypes = [vp, C.c_double]
+    L.qk_set_kill_audio.argtypes = [vp, C.c_int]
+    L.qk_squelch_active.argtypes = [vp, C.c_int]
     L.qk_multirx_graph.argtypes = [vp, vp, C.c_int, vp]
     L.qk_bandscope_init.argtypes = [vp, C.c_int]
     L.qk_add_bscope_samples.argtypes = [vp, vp, C.c_int]
@@ -159,6 +162,17 @@ class Engine:
 
     def set_invert_spectrum(self, on):
         _check(self.L.qk_set_invert_spectrum(self.h, int(bool(on))))
+
+    def set_squelch(self, level_db):
+        """set_squelch (quisk.c:4348-4354): FM squelch level in dB re full scale."""
+        _check(self.L.qk_set_squelch(self.h, float(level_db)))
+
+    def squelch_active(self, rx=0):
+        return _check(self.L.qk_squelch_active(self.h, rx))
+
+    def set_kill_audio(self, on):
+        """set_kill_audio (quisk.c:4364-4370)."""
+        _check(self.L.qk_set_kill_audio(self.h, int(bool(on))))
 
     def set_noise_blanker(self, level):
         """set_noise_blanker (quisk.c:4246-4252): 0 off, 1 / 2 / 3 = pulse limit 6 / 4 / 2.5."""

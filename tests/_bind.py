@@ -108,6 +108,9 @@ def oracle():
     L.qko_rx_set_mode.argtypes = [C.c_void_p, C.c_int]
     L.qko_rx_set_filter.argtypes = [C.c_void_p, ddp, ddp, C.c_int, C.c_int]
     L.qko_rx_set_agc.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.qko_rx_set_squelch.argtypes = [C.c_void_p, C.c_double]
+    L.qko_rx_set_kill_audio.argtypes = [C.c_void_p, C.c_int]
+    L.qko_rx_squelch_active.argtypes = [C.c_void_p]
     L.qko_rx_process.argtypes = [C.c_void_p, cdp, C.c_int]
     L.qko_rx_pre_agc.argtypes = [C.c_void_p, cdp, C.c_int]
     L.qko_rx_agc.argtypes = [C.c_void_p, cdp, C.c_int]
@@ -170,6 +173,15 @@ class OracleRx:
 
     def set_tune(self, hz):
         self.L.qko_rx_set_tune(self.h, hz)
+
+    def set_squelch(self, level_db):
+        self.L.qko_rx_set_squelch(self.h, level_db)
+
+    def set_kill_audio(self, on):
+        self.L.qko_rx_set_kill_audio(self.h, int(on))
+
+    def squelch_active(self):
+        return self.L.qko_rx_squelch_active(self.h)
 
     def _cap(self, n):
         """work-buffer size: the chain runs in place; only a play rate above the input rate makes it grow"""

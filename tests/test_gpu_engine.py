@@ -92,6 +92,53 @@ def test_dgt_iq_stereo(bw, playback, fs):
     assert pr.stereo_seen
 
 
+def test_fm_squelch_and_kill_audio():
+    """FM squelch (quisk.c:1892-1920, 2590-2593): a keyed FM carrier; the receiver is muted, behind its AGC, in the blocks whose
+    measured level is below the threshold, exactly where the oracle mutes; an SSB receiver beside it is never muted;
+    kill_audio silences everything (quisk.c:2585-2589)."""
+    fs, blk, nblk = 192000, 9600, 24
+    tunes, modes = [30000, -41000], [5, 3]
+    rng = np.random.default_rng(12)
+    t = np.arange(blk * nblk)
+    key = np.repeat((np.arange(nblk) // 4) % 2 == 0, blk)                      # four blocks on, four blocks off
+    fm = np.exp(1j * (2 * np.pi * (tunes[0] / fs) * t + 3.0 * np.sin(2 * np.pi * 1000 / fs * t)))
+    x = 2.0 ** 24 * key * fm + 2.0 ** 22 * np.exp(2j * np.pi * ((tunes[1] + 1000) / fs) * t)
+    x = np.round(x + (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t))) * 2.0 ** 12)
+    eng = Engine(fs, n_receivers=2, max_block=blk)
+    configure_engine(eng, modes, tunes)
+    oras = [make_oracle_rx(fs, m, tn) for m, tn in zip(modes, tunes)]
+    level = -60.0
+    eng.set_squelch(level)
+    for o in oras:
+        o.set_squelch(level)
+    muted = []
+    for b in range(nblk):
+        if b == nblk - 2:
+            eng.set_kill_audio(True)
+            for o in oras:
+                o.set_kill_audio(True)
+        part = x[b * blk:(b + 1) * blk]
+        eng.process(part)
+        for r, o in enumerate(oras):
+            want = o.process(part)
+            got = eng.audio(r)
+            assert len(got) == len(want)
+            assert np.array_equal(got == 0, want == 0), (b, r)                  # muted in the same blocks
+            scale = max(float(np.max(np.abs(want))), 1.0)
+            assert float(np.max(np.abs(got - want))) / scale < 1e-4
+            if r == 0 and b < nblk - 2:
+                assert eng.squelch_active(0) == o.squelch_active()
+                muted.append(o.squelch_active())
+            if r == 1 and 0 < b < nblk - 2:
+                assert np.any(got != 0)
+        if b >= nblk - 2:
+            assert not np.any(eng.audio(0)) and not np.any(eng.audio(1))
+    assert 0 < sum(muted) < len(muted)              # closed in some blocks, open in others
+    for o in oras:
+        o.close()
+    eng.close()
+
+
 def test_dgt_bandwidth_change_moves_the_receiver_between_chains():
     """set_filters with a bandwidth across DGT_NARROW_FREQ switches a DGT-U receiver between the two chains; a USB
     receiver beside it is not disturbed."""
