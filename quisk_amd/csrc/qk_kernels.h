@@ -1021,10 +1021,45 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                     hand_over(j, gs, add, pend, true, add, 0, 64);
                     g0 = pend; rmax = nmax; ++j; mp += 64;
                 }
+                const bool ran_out = j >= jend;     // (not: left early for the general step)
                 ir += (j - j0) << 6;
                 while (ir >= a.buf_size) ir -= a.buf_size;
                 if (j < T && j / AGC_CHUNK >= f_known) f_known = uni(peek(&fetched));
                 can = j < T && j / AGC_CHUNK < f_known;
+                if (ran_out && can) {
+                    // The loop stopped at the end of a chunk or in front of the tile with the window boundary in it.  That
+                    // tile is made here, as lean as the loop above (the general step below does the same at twice the cost:
+                    // one tile in eleven): chain up to the boundary with the step constant so far, the new target from the
+                    // window's maximum (quisk.c:2095-2103), chain behind the boundary with the new step constant.
+                    int left = is - ir;
+                    if (left < 0) left += a.buf_size;
+                    bool made = true;
+                    if (left < 64) {
+                        const int bl = left;
+                        const int ws_v = peek(&wstat);
+                        const double mv = sm[(j / AGC_CHUNK) & 1][(j % AGC_CHUNK) * 64 + lane];
+                        double gs = agc_chain<true>(g0, c.keep, add, 0);       // (right up to lane bl; the lanes behind are made again)
+                        double nmax = walk_max(rmax, mv, lane < bl);
+                        const double clip_gain = c.ceil_ / nmax;
+                        const double tnew = c.fm ? clip_gain : (c.rel > clip_gain ? clip_gain : c.rel);
+                        const double add1 = tnew * c.tr;
+                        double pend = readlane_f64(gs, bl) * c.keep + add1;
+                        if (bl < 63) {
+                            const double g2 = agc_chain<true>(pend, c.keep, add1, bl + 1);
+                            if (lane > bl) gs = g2;
+                            pend = readlane_f64(g2, 63) * c.keep + add1;
+                        }
+                        nmax = walk_max(readlane_f64(mv, bl), mv, lane > bl);
+                        made = (unsigned)(j - (uni(ws_v) - (gen << 20))) < (unsigned)AGC_RING;
+                        if (made) {
+                            hand_over(j, gs, add, pend, false, add1, 0, bl);
+                            g0 = pend; add = add1; rmax = nmax; ++j;
+                            ir += 64;
+                            if (ir >= a.buf_size) ir -= a.buf_size;
+                        }
+                    }
+                    if (made) continue;             // back into the loop above (or to whatever the next tile needs)
+                }
             }
             // ---- the general step: one tile, whatever it holds
             const int ws_v = peek(&wstat);
