@@ -99,6 +99,9 @@ struct qk_engine {
     // so the front end of block b+1 runs beside the chain of block b and the AGC of block b-1.
     hipStream_t fe_stream = nullptr;
     hipStream_t agc_stream = nullptr;
+    //   apply_stream : k_agc_apply (gain x delayed sample, limiter) of block b beside the gain pass of block b+1: the gain
+    //                  pass is the pipeline's critical loop, and the 17 us of the apply pass do not belong in it
+    hipStream_t apply_stream = nullptr; hipEvent_t ev_gain = nullptr; double *d_gains2 = nullptr; int *d_agc_started2 = nullptr;
     hipEvent_t ev_chain = nullptr, ev_agc[2] = {nullptr, nullptr};
     hipEvent_t ev_fe = nullptr, ev_fe2 = nullptr;      // front end (and head copy) of this block done (alternating)
     hipEvent_t ev_read[2] = {nullptr, nullptr};        // the chains have finished reading front-stream twin q
@@ -620,6 +623,11 @@ static int init_receivers(qk_engine *e)
     HIPCHECK(hipMemset(e->d_out, 0, nrx * e->out_stride * sizeof(double2)));
     HIPCHECK(hipMalloc(&e->d_gains, nrx * e->gain_stride * sizeof(double)));
     HIPCHECK(hipMalloc(&e->d_agc_mag, nrx * e->gain_stride * sizeof(double)));
+    if (e->apply_stream) {
+        HIPCHECK(hipMalloc(&e->d_gains2, nrx * e->gain_stride * sizeof(double)));
+        HIPCHECK(hipMalloc(&e->d_agc_started2, nrx * sizeof(int)));
+        HIPCHECK(hipMemset(e->d_agc_started2, 0, nrx * sizeof(int)));
+    }
     HIPCHECK(hipMalloc(&e->d_sq_state, nrx * 3 * sizeof(double)));
     HIPCHECK(hipMemset(e->d_sq_state, 0, nrx * 3 * sizeof(double)));
     HIPCHECK(hipMalloc(&e->d_sq_flag, 2 * nrx * sizeof(int)));
@@ -649,6 +657,12 @@ static int engine_init(qk_engine *e)
     HIPCHECK(hipSetDevice(cfg.device));
     HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIPCHECK(hipStreamCreateWithFlags(&e->agc_stream, hipStreamNonBlocking));
+    bool apply_own = true;      // (QK_APPLY_STREAM=0: the limiter pass stays on the AGC's stream)
+    if (const char *v = getenv("QK_APPLY_STREAM")) apply_own = atoi(v) != 0;
+    if (apply_own) {
+        HIPCHECK(hipStreamCreateWithFlags(&e->apply_stream, hipStreamNonBlocking));
+        HIPCHECK(hipEventCreateWithFlags(&e->ev_gain, hipEventDisableTiming));
+    }
     HIPCHECK(hipStreamCreateWithFlags(&e->fe_stream, hipStreamNonBlocking));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_fe, hipEventDisableTiming));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_fe2, hipEventDisableTiming));
@@ -1382,7 +1396,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             m_max = std::max(m_max, a.n_c[cl]);
         }
         if (m_max > 0) {
-            a.cls = e->d_cls; a.gains = e->d_gains; a.gain_stride = e->gain_stride;
+            a.cls = e->d_cls; a.gains = (e->apply_stream && par) ? e->d_gains2 : e->d_gains; a.gain_stride = e->gain_stride;
             a.buf_size = rate * 15 / 1000; a.n_rx = e->nrx;
             a.ceiling = 0.7 * QK_CLIP32;                                         // Agc1 max_out, quisk.c:2181
             a.time_release = 1.0 - exp(-1.0 / rate / e->agc_release_time);       // quisk.c:2045
@@ -1393,16 +1407,25 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             Timer tm(e, QK_KT_AGC, e->agc_stream);
             if (any_cpx) hipLaunchKernelGGL(k_agc_cabs, grid1(m_max, 1, e->nrx), dim3(256), 0, e->agc_stream, a);
             hipLaunchKernelGGL(k_agc_gain, dim3(e->nrx), dim3(192), 0, e->agc_stream, a);
-            hipLaunchKernelGGL(k_agc_apply, grid1(m_max, 1, e->nrx), dim3(256), 0, e->agc_stream, a);
+            hipStream_t aps = e->agc_stream;
+            if (e->apply_stream) {
+                HIPCHECK(hipEventRecord(e->ev_gain, e->agc_stream));
+                HIPCHECK(hipStreamWaitEvent(e->apply_stream, e->ev_gain, 0));
+                aps = e->apply_stream;
+                a.started = e->d_agc_started2;
+            }
+            hipLaunchKernelGGL(k_agc_apply, grid1(m_max, 1, e->nrx), dim3(256), 0, aps, a);
             for (int cl = 0; cl < CL_COUNT; cl++) {
                 if (a.n_c[cl] <= 0) continue;
                 for (int r : e->cls_chain[cl].members)
-                    if (!e->agc_started[r])
+                    if (!e->agc_started[r]) {
                         hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_agc_started + r), 1, 1, e->agc_stream);
+                        if (e->apply_stream) hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_agc_started2 + r), 1, 1, aps);
+                    }
             }
         }
     }
-    HIPCHECK(hipEventRecord(e->ev_agc[par], e->agc_stream));
+    HIPCHECK(hipEventRecord(e->ev_agc[par], e->apply_stream ? e->apply_stream : e->agc_stream));
     // ---- carry stream tails ----
     {
         TailArgs ta{}; ta.count = 0; ta.rx_list = nullptr;
@@ -1476,6 +1499,7 @@ void qk_destroy(qk_engine *e)
     if (e->fe_stream) hipStreamSynchronize(e->fe_stream);
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->agc_stream) hipStreamSynchronize(e->agc_stream);
+    if (e->apply_stream) hipStreamSynchronize(e->apply_stream);
     free_chain(e->front);
     for (auto &c : e->cls_chain) free_chain(c);
     blue_free(e->blue);
@@ -1493,6 +1517,10 @@ void qk_destroy(qk_engine *e)
     for (void *p : ptrs) if (p) hipFree(p);
     for (auto &ev : e->ev_pool) if (ev) hipEventDestroy(ev);
     if (e->agc_stream) { hipStreamSynchronize(e->agc_stream); hipStreamDestroy(e->agc_stream); }
+    if (e->apply_stream) { hipStreamSynchronize(e->apply_stream); hipStreamDestroy(e->apply_stream); }
+    if (e->ev_gain) hipEventDestroy(e->ev_gain);
+    if (e->d_gains2) hipFree(e->d_gains2);
+    if (e->d_agc_started2) hipFree(e->d_agc_started2);
     if (e->ev_chain) hipEventDestroy(e->ev_chain);
     for (auto &ev : e->ev_agc) if (ev) hipEventDestroy(ev);
     if (e->ev_fe) hipEventDestroy(e->ev_fe);
@@ -1508,7 +1536,8 @@ void qk_destroy(qk_engine *e)
     std::lock_guard<std::mutex> _lk((e)->mu);                            \
     HIPCHECK(hipSetDevice((e)->cfg.device))
 #define SYNC_ALL(e) do { HIPCHECK(hipStreamSynchronize((e)->fe_stream)); HIPCHECK(hipStreamSynchronize((e)->stream)); \
-                         HIPCHECK(hipStreamSynchronize((e)->agc_stream)); } while (0)
+                         HIPCHECK(hipStreamSynchronize((e)->agc_stream)); \
+                         if ((e)->apply_stream) HIPCHECK(hipStreamSynchronize((e)->apply_stream)); } while (0)
 #define RX_CHECK(e, rx) if ((rx) < 0 || (rx) >= (e)->nrx) return fail(QK_ERANGE, "receiver index out of range")
 
 int qk_set_tune(qk_engine *e, int rx, int tune_hz)
@@ -1719,6 +1748,7 @@ int qk_pull_audio(qk_engine *e, int rx, double *dst, int cap)
 {
     ENGINE_ENTER(e); RX_CHECK(e, rx);
     HIPCHECK(hipStreamSynchronize(e->agc_stream));       // the AGC pass writes the audio output
+    if (e->apply_stream) HIPCHECK(hipStreamSynchronize(e->apply_stream));
     const int m = std::min(e->out_count[rx], cap);
     if (m > 0) {
         if (!dst) return fail(QK_EINVAL, "null destination");
@@ -1733,6 +1763,7 @@ int qk_pull_audio_all(qk_engine *e, double *dst, size_t stride, int *counts)
 {
     ENGINE_ENTER(e);
     HIPCHECK(hipStreamSynchronize(e->agc_stream));       // the AGC pass writes the audio output
+    if (e->apply_stream) HIPCHECK(hipStreamSynchronize(e->apply_stream));
     if (!dst || !counts) return fail(QK_EINVAL, "null destination");
     for (int r = 0; r < e->nrx; r++) {
         const int m = e->out_count[r];
@@ -1920,6 +1951,7 @@ int qk_export_audio_device(qk_engine *e, double *dst_dev, size_t dst_stride)
 {
     ENGINE_ENTER(e);
     HIPCHECK(hipStreamSynchronize(e->agc_stream));       // the AGC pass writes the audio output
+    if (e->apply_stream) HIPCHECK(hipStreamSynchronize(e->apply_stream));
     if (!dst_dev) return fail(QK_EINVAL, "null destination");
     size_t w = 0;
     for (int r = 0; r < e->nrx; r++) w = std::max(w, (size_t)e->out_count[r]);
@@ -1992,6 +2024,7 @@ long long qk_debug_agc_passes(qk_engine *e, int rx)
     std::lock_guard<std::mutex> lk(e->mu);
     hipSetDevice(e->cfg.device);
     hipStreamSynchronize(e->fe_stream); hipStreamSynchronize(e->stream); hipStreamSynchronize(e->agc_stream);
+    if (e->apply_stream) hipStreamSynchronize(e->apply_stream);
     AgcState st;
     if (hipMemcpy(&st, e->d_agc + rx, sizeof st, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return st.pad;
