@@ -136,7 +136,7 @@ struct qk_engine {
     double *d_taps = nullptr; int *d_ntaps = nullptr, *d_mode = nullptr, *d_cls = nullptr; double *d_release_gain = nullptr;
     std::vector<int> ntaps, bandwidth, start_offset;
     // FM squelch and kill_audio: d_sq_state [rx][3], d_sq_flag [2][rx] (one set per block in flight towards the AGC)
-    double squelch_level = -999.0; int kill_audio = 0; double *d_sq_state = nullptr; int *d_sq_flag = nullptr;
+    double squelch_level = -999.0; int kill_audio = 0; double *d_sq_state = nullptr, *d_sq_partial = nullptr; int *d_sq_flag = nullptr, sq_pstride = 0;
     AgcState *d_agc = nullptr; double *d_gains = nullptr, *d_agc_mag = nullptr; int gain_stride = 0;   // d_agc_mag: [rx][gain_stride] cabs of complex play streams
     int *d_agc_started = nullptr; std::vector<char> agc_started;    // per receiver: has process_agc run once?
     double agc_release_time = 1.0;
@@ -630,6 +630,8 @@ static int init_receivers(qk_engine *e)
     }
     HIPCHECK(hipMalloc(&e->d_sq_state, nrx * 3 * sizeof(double)));
     HIPCHECK(hipMemset(e->d_sq_state, 0, nrx * 3 * sizeof(double)));
+    e->sq_pstride = cfg.max_block / 256 + 8;        // the discriminator's workgroups: its stream is never longer than the input block
+    HIPCHECK(hipMalloc(&e->d_sq_partial, (size_t)nrx * e->sq_pstride * sizeof(double)));
     HIPCHECK(hipMalloc(&e->d_sq_flag, 2 * nrx * sizeof(int)));
     HIPCHECK(hipMemset(e->d_sq_flag, 0, 2 * nrx * sizeof(int)));
     // class chains are built when a receiver first enters the class (all receivers start as USB).  Their
@@ -1117,19 +1119,20 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
                 const int tqp = std::max(FT_QB, (nmax + FT_QB - 1) / FT_QB * FT_QB);
                 const dim3 grid((n_in + FT_NTH * FT_R - 1) / (FT_NTH * FT_R), 1, nlist);
                 hipLaunchKernelGGL((k_rxf_tiled<FT_NTH, FT_R>), grid, dim3(FT_NTH), sizeof(double) * (FT_NTH * FT_R + tqp), e->stream, a);
-                if (&c == &e->cls_chain[CL_FM]) {       // the FM squelch measures the filtered samples (quisk.c:1892)
-                    SquelchArgs q{out.view(), n_in, d_list, e->d_sq_state, e->d_sq_flag + (e->stats.blocks & 1) * e->nrx, e->squelch_level};
-                    hipLaunchKernelGGL(k_fm_squelch, dim3(nlist), dim3(256), 0, e->stream, q);
-                }
             }
             break;
         }
         case ST_FMDISC: {
             out.n = n_in;
             if (n_in > 0) {
-                FmDiscArgs a{in.view(), out.view(), n_in, st.fs, d_list};
+                const int np = (n_in + 255) / 256;      // = grid1's x extent
+                FmDiscArgs a{in.view(), out.view(), n_in, st.fs, d_list, e->d_sq_partial, e->sq_pstride};
                 Timer tm(e, st.timer);
                 hipLaunchKernelGGL(k_fm_disc, grid1(n_in, 1, nlist), dim3(256), 0, e->stream, a);
+                // the FM squelch measures the filtered samples (quisk.c:1892, 1911-1920)
+                SquelchArgs q{e->d_sq_partial, e->sq_pstride, np, n_in, d_list, e->d_sq_state, e->d_sq_flag + (e->stats.blocks & 1) * e->nrx,
+                              e->squelch_level};
+                hipLaunchKernelGGL(k_fm_squelch, dim3(nlist), dim3(256), 0, e->stream, q);
             }
             break;
         }
@@ -1511,7 +1514,7 @@ void qk_destroy(qk_engine *e)
     for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
     void *ptrs[] = {e->d_nb_x[0], e->d_nb_x[1], e->d_nb_mag[0], e->d_nb_mag[1], e->d_nb_p[0], e->d_nb_p[1], e->d_nb_y, e->d_nb_loc, e->d_nb_segsum,
                     e->d_nb_segbase, e->d_nb_S, e->d_nb_words, e->d_nb_any, e->d_cond, e->d_dc_seg_end, e->d_dc_seg_in, e->d_dc_state, e->d_dc_partial, e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps, e->d_cls,
-                    e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_agc_mag, e->d_sq_state, e->d_sq_flag, e->d_out,
+                    e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_agc_mag, e->d_sq_state, e->d_sq_partial, e->d_sq_flag, e->d_out,
                     e->d_fft_stage, e->d_fft_Y, e->d_tw4096, e->d_tw_lo, e->d_tw_hi, e->d_window, e->d_fft_avg, e->d_band,
                     e->d_meter, e->d_graph, e->d_pix, e->d_k0};
     for (void *p : ptrs) if (p) hipFree(p);

@@ -624,31 +624,41 @@ __global__ __launch_bounds__(NTH) void k_rxf_tiled(RxfArgs a)
 }
 
 // FM discriminator (quisk.c:1894-1896): d = fs * arg(c[i] conj(c[i-1])); c[-1] of the very first block is 10.
-struct FmDiscArgs { StreamView in, out; int n; double fs; const int *rx_list; };
+struct FmDiscArgs { StreamView in, out; int n; double fs; const int *rx_list; double *partial; int pstride; };   // partial: [rx][pstride] sums of |c| per workgroup, for the squelch
 __global__ __launch_bounds__(256) void k_fm_disc(FmDiscArgs a)
 {
+    __shared__ double red[256];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
     const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
-    const double *pr = sv_ptr(a.in, rx, 0) + i, *pi = sv_ptr(a.in, rx, 1) + i;
-    const double cr = pr[0], ci = pi[0], qr = pr[-1], qi = pi[-1];
-    const double re = cr * qr + ci * qi;       // c * conj(q)
-    const double im = ci * qr - cr * qi;
-    sv_ptr(a.out, rx, 0)[i] = a.fs * atan2(im, re);
+    double mag = 0.0;
+    if (i < a.n) {
+        const double *pr = sv_ptr(a.in, rx, 0) + i, *pi = sv_ptr(a.in, rx, 1) + i;
+        const double cr = pr[0], ci = pi[0], qr = pr[-1], qi = pi[-1];
+        const double re = cr * qr + ci * qi;       // c * conj(q)
+        const double im = ci * qr - cr * qi;
+        sv_ptr(a.out, rx, 0)[i] = a.fs * atan2(im, re);
+        mag = hypot(cr, ci);                        // rf_sum of the FM squelch, quisk.c:1892
+    }
+    red[threadIdx.x] = mag;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.partial[(long long)rx * a.pstride + blockIdx.x] = red[0];
 }
 
 // FM squelch (quisk.c:1892-1893, 1911-1920): the mean magnitude of the filtered samples over stretches of at least 2400
 // samples, closed at block ends as in the reference, in dB re full scale; the receiver is muted while it is below the
-// level.  One workgroup per receiver; the block's sum is a fixed-order tree (the reference adds sample by sample: the
+// level.  The block's sum is a fixed-order tree over the discriminator's workgroups (the reference adds sample by sample: the
 // sums differ in the last bits, the decision only if the level is met to 1e-13 dB).
-struct SquelchArgs { StreamView in; int n; const int *rx_list; double *state; int *flag; double level; };   // state: [rx][3] sum, count, dB
+struct SquelchArgs { const double *partial; int pstride, np, n; const int *rx_list; double *state; int *flag; double level; };   // state: [rx][3] sum, count, dB
 __global__ __launch_bounds__(256) void k_fm_squelch(SquelchArgs a)
 {
     __shared__ double red[256];
     const int rx = a.rx_list ? a.rx_list[blockIdx.x] : blockIdx.x;
-    const double *pr = sv_ptr(a.in, rx, 0), *pi = sv_ptr(a.in, rx, 1);
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < a.n; i += 256) acc += hypot(pr[i], pi[i]);
+    double acc = 0.0;       // the discriminator's workgroups left the sums of |c| of their 256 samples
+    for (int i = threadIdx.x; i < a.np; i += 256) acc += a.partial[(long long)rx * a.pstride + i];
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
