@@ -101,7 +101,7 @@ struct qk_engine {
     hipStream_t agc_stream = nullptr;
     //   apply_stream : k_agc_apply (gain x delayed sample, limiter) of block b beside the gain pass of block b+1: the gain
     //                  pass is the pipeline's critical loop, and the 17 us of the apply pass do not belong in it
-    hipStream_t apply_stream = nullptr; hipEvent_t ev_gain = nullptr; double *d_gains2 = nullptr; int *d_agc_started2 = nullptr;
+    hipStream_t apply_stream = nullptr; bool last_apply_own = false; hipEvent_t ev_gain = nullptr; double *d_gains2 = nullptr; int *d_agc_started2 = nullptr;
     hipEvent_t ev_chain = nullptr, ev_agc[2] = {nullptr, nullptr};
     hipEvent_t ev_fe = nullptr, ev_fe2 = nullptr;      // front end (and head copy) of this block done (alternating)
     hipEvent_t ev_read[2] = {nullptr, nullptr};        // the chains have finished reading front-stream twin q
@@ -1382,6 +1382,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         e->read_pending[q] = true;
         e->fe_blocks++;
     }
+    hipStream_t agc_ev_stream = e->agc_stream;
     {
         static_assert(CL_COUNT <= QK_AGC_CLASSES, "AgcArgs holds one stream view per chain class");
         const int rate = e->cfg.playback_rate;
@@ -1411,7 +1412,14 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             if (any_cpx) hipLaunchKernelGGL(k_agc_cabs, grid1(m_max, 1, e->nrx), dim3(256), 0, e->agc_stream, a);
             hipLaunchKernelGGL(k_agc_gain, dim3(e->nrx), dim3(192), 0, e->agc_stream, a);
             hipStream_t aps = e->agc_stream;
-            if (e->apply_stream) {
+            // (short blocks are bound by the host's launches, and the second stream costs two more calls: it is used from
+            // 4096 audio samples per receiver on)
+            const bool own = e->apply_stream && m_max >= 4096;
+            if (!own && e->last_apply_own && e->agc_pending)
+                HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_agc[par ^ 1], 0));      // the previous apply pass, on the other stream
+            e->last_apply_own = own;
+            agc_ev_stream = own ? e->apply_stream : e->agc_stream;
+            if (own) {
                 HIPCHECK(hipEventRecord(e->ev_gain, e->agc_stream));
                 HIPCHECK(hipStreamWaitEvent(e->apply_stream, e->ev_gain, 0));
                 aps = e->apply_stream;
@@ -1428,7 +1436,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             }
         }
     }
-    HIPCHECK(hipEventRecord(e->ev_agc[par], e->apply_stream ? e->apply_stream : e->agc_stream));
+    HIPCHECK(hipEventRecord(e->ev_agc[par], agc_ev_stream));
     // ---- carry stream tails ----
     {
         TailArgs ta{}; ta.count = 0; ta.rx_list = nullptr;
