@@ -130,6 +130,12 @@ def test_noise_blanker_with_dc_blocker_and_inversion_at_1536k():
     _run(fs, 3, 300000, [65536, 100001, 1023, 65536], 100, True, 5, nb=2, pulses=_pulse_train(fs, 7))
 
 
+def test_noise_blanker_at_48k_tiny_blocks():
+    """The smallest half window (24 samples at 48 ksps: the history is one segment) and blocks of a few samples."""
+    fs = 48000
+    _run(fs, 3, 5000, [4800, 1, 2, 63, 64, 65, 4800, 333, 4800, 4800], 0, False, 31, nb=3, pulses=_pulse_train(fs, 41))
+
+
 def test_noise_blanker_on_quiet_input_only_delays():
     """No pulses: behind its start-up the blanker is a delay line of 3 x 500 us."""
     fs = 192000
