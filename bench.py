@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the receive-DSP hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): 64 SSB receivers per GPU on one 1.536 Msps complex-double I/Q stream,
+Headline workload (BASELINE.json configs[1]): 64 SSB receivers per GPU on one 1.536 Msps complex-double I/Q stream,
 cascaded decimating FIRs, SSB demodulation, AGC, fp64.  A "step" is one pass of the whole receive chain
 (quisk_process_samples for every receiver) over one block of `--block` synthetic I/Q samples that are already
 resident in HBM.  value = input samples processed per second (summed over ranks) / 1e6.
 
-Multi-GPU (`--gpus N`, launched by torch.distributed.run): receivers are sharded, 64 per rank, every rank reads
-the same I/Q stream (weak scaling, no data-path collective).  The audio gather over RCCL that the north star
-asks for is exercised once after the timed region and timed separately (`gather_ms`).
+Further legs in the same JSON line (each with its own roofline object):
+  config4_slice  the per-GPU share of configs[3]: 128 mixed SSB/AM/FM receivers at 61.44 Msps, 2^20-sample blocks; with
+                 N > 1 ranks the audio of all receivers is gathered to rank 0 over RCCL and that gather is timed
+  spectrum       configs[2]: 2^20-point windowed, averaged display FFT at 61.44 Msps (rank 0), CPU FFT timed beside it
+  config1        configs[0]: 1 USB receiver at 192 ksps in 960-sample blocks, engine beside the single-threaded CPU port
+  cpu_baseline   the CPU port (oracle) of the headline workload on the host cores (rank 0, N = 1 only)
+
+Multi-GPU: `python bench.py --gpus N` with no RANK in the environment starts N ranks itself (torch.distributed.run,
+one process per GPU, before anything here touches a GPU); under a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.
+Receivers are sharded, `--receivers` per rank, every rank reads the same I/Q stream (weak scaling, no data-path
+collective).
 
 Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,27 +35,42 @@ sys.path.insert(0, ROOT)
 
 FE_FLOPS_PER_SAMPLE = {0: 12.0, 1: 12 + 34.0, 2: 12 + 34 * 1.5, 3: 12 + 34 * 1.75, 4: 12 + 34 * 1.875, 5: 12 + 34 * 1.9375}
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X FP64 vector peak: half the 157.3 TF FP32 vector rate of MI355X_MICROARCH.md
+FP32_VALU_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)     # 200 blocks of 2^20 samples = 0.09 s of GPU time: fill and drain of the
+    ap.add_argument("--steps", type=int, default=200)     # 200 blocks of 2^20 samples = 0.08 s of GPU time: fill and drain of the
     ap.add_argument("--warmup", type=int, default=10)     # three-deep pipeline are 1 % of it (they are 4 % of 40 steps)
     ap.add_argument("--block", type=int, default=1 << 20, help="I/Q samples per step")
     ap.add_argument("--receivers", type=int, default=64, help="receivers per GPU")
     ap.add_argument("--rate", type=int, default=1536000)
     ap.add_argument("--mix", default="ssb", choices=["ssb", "mixed"])
+    ap.add_argument("--fp32", action="store_true", help="run the headline leg in the engine's fp32 mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spectrum", action="store_true", help="skip the configs[2] spectrum leg")
+    ap.add_argument("--no-config4", action="store_true", help="skip the configs[3] per-GPU slice leg")
+    ap.add_argument("--no-config1", action="store_true", help="skip the configs[0] leg")
     ap.add_argument("--cpu-samples", type=int, default=1 << 21)
     return ap.parse_args()
 
 
+def launch_ranks(a):
+    """`--gpus N` without a launcher: become the launcher.  Nothing in this process has touched a GPU yet."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+# ------------------------------------------------------------------------------------------------ CPU legs
 def cpu_baseline(fs, modes, tunes, n_samples, seed):
     """The oracle (CPU restatement of the reference's per-sample loops, kind "port") on the host cores:
-    one receiver per thread, blocks of 65536 like config 2."""
+    one receiver per thread, blocks of 65536 like config 2.  Test infrastructure used as the checker's clock only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from concurrent.futures import ThreadPoolExecutor
     from _rxsetup import make_oracle_rx
@@ -70,12 +95,102 @@ def cpu_baseline(fs, modes, tunes, n_samples, seed):
                       % (len(modes), n_samples, n_samples / fs)}
 
 
-def spectrum_leg(local, dev_block_ptrs, block):
+def cpu_fft_baseline(N, frames_single=3, frames_multi=16):
+    """The oracle's FFT (FFTW is not in the image; the reference's FFT cannot travel) with the Hann window and the
+    magnitude accumulation of get_graph: frames/s on one thread and on all the box's cores (one frame per thread)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from concurrent.futures import ThreadPoolExecutor
+    import _bind as B
+    rng = np.random.default_rng(1003)
+    x = (rng.standard_normal(N) + 1j * rng.standard_normal(N)) * 2.0 ** 20
+    cores = max(1, min(16, os.cpu_count() or 1))
+
+    def frame(_):
+        g = B.OracleGraph(N, 4096, 61440000)
+        g.add_frames(x)
+        g.close()
+
+    frame(0)
+    t0 = time.time()
+    for i in range(frames_single):
+        frame(i)
+    single = frames_single / (time.time() - t0)
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(frame, range(frames_multi)))
+    multi = frames_multi / (time.time() - t0)
+    return {"value": multi, "unit": "frames/s", "cores": cores, "kind": "port", "single_thread_frames_per_s": single,
+            "sample": "%d + %d frames of %d points: window, FFT (the oracle's radix-2; FFTW is absent), |X| accumulation"
+                      % (frames_single, frames_multi, N)}
+
+
+# ------------------------------------------------------------------------------------------------ GPU legs
+def make_engine(fs, nrx, block, local, tunes, modes, fp32=False, **kw):
+    from quisk_amd import Engine, rx_filter
+    eng = Engine(fs, n_receivers=nrx, max_block=block, device=local, fp32=fp32, **kw)
+    for r in range(nrx):
+        fi, fq, bw, off = rx_filter(fs, int(modes[r]))
+        eng.set_mode(r, int(modes[r]))
+        eng.set_tune(r, int(tunes[r]))
+        eng.set_filters(r, fi, fq, bw, off)
+    return eng
+
+
+def timed_leg(eng, ptrs, block, steps, warmup, barrier, timing_groups):
+    """W untimed steps, then exactly K steps between barriers; returns (seconds, stats)."""
+    nb = len(ptrs)
+    for i in range(warmup):
+        eng.process_device(ptrs[i % nb], block)
+    eng.sync()
+    eng.reset_stats()
+    eng.set_timing(True, groups=timing_groups)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.process_device(ptrs[i % nb], block)
+    eng.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    st = eng.stats()
+    eng.set_timing(False)
+    return dt, st
+
+
+def frontend_roofline(st, fs, block, nrx, dt_step_ms, fp32, pmc_name):
+    from quisk_amd import plan_decimation
+    from quisk_amd.engine import KT_FRONTEND
+    _, d2, _, _ = plan_decimation(fs)
+    S = min(max(d2 - 1, 0), 5)
+    fe_ms = st.kernel_ms_sum[KT_FRONTEND] / max(1, st.kernel_launches[KT_FRONTEND])
+    fe_flops = FE_FLOPS_PER_SAMPLE[S] * block * nrx
+    achieved_tf = fe_flops / (fe_ms * 1e-3) / 1e12 if fe_ms > 0 else 0.0
+    peak = FP32_VALU_PEAK_TFLOPS if fp32 else FP64_VALU_PEAK_TFLOPS
+    traffic, source = None, None
+    pmc = os.path.join(ROOT, "profiles", pmc_name)
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            source = "profiles/%s (rocprofv3 --pmc passes of an earlier run of this command, not this run)" % pmc_name
+        except Exception:
+            traffic = None
+    esz = 8 if fp32 else 16
+    return {"kernel": "k_frontend_wave<S=%d> (mixer + %d fused half-band decimators)" % (S, S),
+            "bound": "valu", "pipe": "fp32 vector FMA" if fp32 else "fp64 vector FMA", "achieved": achieved_tf, "peak": peak,
+            "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic, "traffic_source": source,
+            "avg_launch_ms": fe_ms, "launches": int(st.kernel_launches[KT_FRONTEND]),
+            "algorithmic_flop_per_launch": fe_flops,
+            "hbm": {"achieved": (16.0 * block + esz * (block >> S) * nrx) / (fe_ms * 1e-3) / 1e9 if fe_ms > 0 else 0.0,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+            "share_of_step": fe_ms / dt_step_ms if dt_step_ms > 0 else None}
+
+
+def spectrum_leg(local, dev_block_ptrs, block, with_cpu):
     """BASELINE configs[2]: 2^20-point periodic-Hann windowed FFT at 61.44 Msps, magnitude average of 8 frames
     released as a 4096-point dB row (get_graph).  Frames come from the blocks already resident in HBM.
-    Reported beside the headline number: frames/s and the algorithmic HBM rate (16 B per sample read once)."""
+    Reported: frames/s, the algorithmic HBM rate (16 B per sample read once) and the FFT kernels' own time."""
     import torch
     from quisk_amd import Engine
+    from quisk_amd.engine import KT_FFT
     N = 1 << 20
     if block < N:
         return None
@@ -85,25 +200,101 @@ def spectrum_leg(local, dev_block_ptrs, block):
         eng.process_device(dev_block_ptrs[i % len(dev_block_ptrs)], N)
     _, row, _ = eng.get_graph(1.0, 0.0)
     torch.cuda.synchronize()
-    groups, t0 = 6, time.perf_counter()
+    groups, t0 = 12, time.perf_counter()
     for g in range(groups):
         for i in range(8):
             eng.process_device(dev_block_ptrs[i % len(dev_block_ptrs)], N)
         _, row, _ = eng.get_graph(1.0, 0.0)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the kernels' own time, from HIP events on the stream they run on (a second, shorter pass: events cost queue time)
+    eng.reset_stats()
+    eng.set_timing(True, groups=(KT_FFT,))
+    for i in range(16):
+        eng.process_device(dev_block_ptrs[i % len(dev_block_ptrs)], N)
+    eng.get_graph(1.0, 0.0)
+    st = eng.stats()
+    eng.set_timing(False)
+    k_ms = st.kernel_ms_sum[KT_FFT] / max(1, st.kernel_launches[KT_FFT])
     eng.close()
     fps = groups * 8 / dt
     gbs = fps * N * 16.0 / 1e9
-    return {"workload": "BASELINE configs[2]: 2^20-point windowed FFT at 61.44 Msps, 8-frame magnitude average, 4096-point dB row",
-            "frames_per_s": fps, "realtime_frames_per_s": 61440000.0 / N, "msamples_per_s": fps * N / 1e6,
-            "row_finite": bool(row is not None and np.isfinite(row).all()),
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_frame": N * 16.0}}
+    k_gbs = N * 16.0 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic, source = None, None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_fft.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_frame")
+            source = "profiles/r02_pmc_fft.json (rocprofv3 --pmc passes of an earlier run, not this run)"
+        except Exception:
+            traffic = None
+    res = {"workload": "BASELINE configs[2]: 2^20-point windowed FFT at 61.44 Msps, 8-frame magnitude average, 4096-point dB row",
+           "frames_per_s": fps, "realtime_frames_per_s": 61440000.0 / N, "msamples_per_s": fps * N / 1e6,
+           "row_finite": bool(row is not None and np.isfinite(row).all()),
+           "roofline": {"kernel": "the FFT passes of one frame (k_fft_*), HIP events on their stream", "bound": "hbm",
+                        "achieved": k_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k_gbs / HBM_PEAK_GBS,
+                        "avg_frame_kernels_ms": k_ms, "traffic": traffic, "traffic_source": source,
+                        "algorithmic_bytes_per_frame": N * 16.0,
+                        "whole_leg": {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS,
+                                      "note": "frames/s x 16 B x 2^20 over wall time, release and host calls included"}}}
+    if with_cpu:
+        res["cpu_baseline"] = cpu_fft_baseline(N)
+    return res
+
+
+def config1_leg(local, with_cpu):
+    """BASELINE configs[0]: 1 USB receiver on a 192 ksps stream, 960-sample blocks (the reference's 5 ms poll), 4096-point
+    graph FFT: the engine fed host blocks one after the other (launch-bound at this size) beside the CPU port on one thread
+    (the reference runs this on its single sound thread)."""
+    from quisk_amd import Engine, rx_filter
+    from quisk_amd.synth import make_iq
+    fs, blk, nblk = 192000, 960, 1000
+    tune, mode = int(0.1 * fs), 3
+    x = make_iq(blk * nblk, fs, [tune], [mode], 1001)
+    eng = Engine(fs, n_receivers=1, max_block=blk, fft_size=4096, data_width=4096, device=local)
+    fi, fq, bw, off = rx_filter(fs, mode)
+    eng.set_mode(0, mode); eng.set_tune(0, tune); eng.set_filters(0, fi, fq, bw, off)
+    out = np.empty(eng.out_cap, dtype=np.complex128)
+    for i in range(20):
+        eng.process(x[i * blk:(i + 1) * blk])
+    eng.sync()
+    t0 = time.perf_counter()
+    frames = 0
+    for i in range(nblk):
+        eng.process(x[i * blk:(i + 1) * blk])
+        eng.L.qk_pull_audio(eng.h, 0, out.ctypes.data, eng.out_cap)     # audio back on the host every block, as the sound loop needs it
+        if i % 10 == 9:
+            frames += eng.get_graph(1.0, 0.0)[0]
+    eng.sync()
+    dt = time.perf_counter() - t0
+    eng.close()
+    res = {"workload": "BASELINE configs[0]: 1 USB receiver, 192 ksps, 960-sample host blocks, audio pulled every block, 4096-point graph",
+           "msamples_per_s": blk * nblk / dt / 1e6, "realtime_factor": blk * nblk / dt / fs, "ms_per_block": dt / nblk * 1e3,
+           "fft_frames": frames, "note": "launch-bound: one 5 ms block is ~25 kernel launches and two synchronisations"}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _bind as B
+        from _rxsetup import make_oracle_rx
+        o = make_oracle_rx(fs, mode, tune)
+        g = B.OracleGraph(4096, 4096, fs)
+        t0 = time.perf_counter()
+        for i in range(nblk):
+            o.process(x[i * blk:(i + 1) * blk])
+        for i in range(0, blk * nblk - 4095, 4096):
+            g.add_frames(x[i:i + 4096])
+        g.release()
+        cdt = time.perf_counter() - t0
+        o.close(); g.close()
+        res["cpu_baseline"] = {"value": blk * nblk / cdt / 1e6, "unit": "input Msamples/s at 1 receiver", "cores": 1, "kind": "port",
+                               "realtime_factor": blk * nblk / cdt / fs,
+                               "sample": "%d blocks of 960 samples (5 s of signal) + %d graph frames, one thread" % (nblk, blk * nblk // 4096)}
+    return res
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -114,27 +305,21 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == world
+    if a.gpus != world:
+        raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (a.gpus, world))
 
-    from quisk_amd import Engine
     from quisk_amd.engine import KT_FRONTEND
     from quisk_amd.synth import make_iq, tune_offsets, mode_mix
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from _rxsetup import rx_filter
+    from quisk_amd.shard import receiver_slice, gather_audio, max_over_ranks
 
     fs, nrx, block = a.rate, a.receivers, a.block
     total_rx = nrx * world
     all_tunes = tune_offsets(total_rx, fs)
     all_modes = mode_mix(total_rx, a.mix)
-    from quisk_amd.shard import receiver_slice, gather_audio, max_over_ranks
     lo, hi = receiver_slice(total_rx, world, rank)
     tunes, modes = all_tunes[lo:hi], all_modes[lo:hi]
-
-    eng = Engine(fs, n_receivers=nrx, max_block=block, device=local)
-    for r in range(nrx):
-        fi, fq, bw, off = rx_filter(fs, int(modes[r]))
-        eng.set_mode(r, int(modes[r]))
-        eng.set_tune(r, int(tunes[r]))
-        eng.set_filters(r, fi, fq, bw, off)
+    eng = make_engine(fs, nrx, block, local, tunes, modes, fp32=a.fp32)
 
     # synthetic stream resident in HBM: NB distinct blocks (the base block rotated by a different phase each),
     # 256 MiB in total so that successive steps do not re-read a cache-resident input
@@ -151,81 +336,75 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        eng.process_device(ptrs[i % nb], block)
-    eng.sync()
-    eng.reset_stats()
-    eng.set_timing(True, groups=(KT_FRONTEND,))      # HIP events around the front-end kernel only
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        eng.process_device(ptrs[i % nb], block)
-    eng.sync()
-    barrier()
-    dt = time.perf_counter() - t0
-    st = eng.stats()
-    eng.set_timing(False)
-    dt = max_over_ranks(dt, torch.device("cuda", local))
-
-    # RCCL gather of the audio outputs (outside the timed region)
-    gather_ms = None
-    if world > 1:
-        counts = torch.tensor([eng.L.qk_audio_count(eng.h, r) for r in range(nrx)], dtype=torch.int64, device="cuda")
+    def gather_outputs(e, n_local):
+        """RCCL gather of the last block's audio of every receiver to rank 0 (the only collective of the path)."""
+        counts = torch.tensor([e.L.qk_audio_count(e.h, r) for r in range(n_local)], dtype=torch.int64, device="cuda")
         stride = int(counts.max().item())
-        send = torch.empty((nrx, stride, 2), dtype=torch.float64, device="cuda")
-        eng.export_audio_device(send.data_ptr(), stride)
-        torch.cuda.synchronize()
+        send = torch.empty((n_local, stride, 2), dtype=torch.float64, device="cuda")
+        e.export_audio_device(send.data_ptr(), stride)
+        barrier()
         g0 = time.perf_counter()
         audio, cnt = gather_audio(send, counts, dst=0)
         torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
+        ms = (time.perf_counter() - g0) * 1e3
         if rank == 0:
-            assert audio.shape[0] == total_rx and int(cnt.min().item()) > 0
+            assert audio.shape[0] == n_local * world and int(cnt.min().item()) > 0
+        return {"ms": ms, "bytes": int(n_local * world * stride * 16), "receivers": n_local * world}
 
-    from quisk_amd import plan_decimation
-    _, d2, _, _ = plan_decimation(fs)
-    S = min(max(d2 - 1, 0), 5)
-    fe_ms = st.kernel_ms_sum[KT_FRONTEND] / max(1, st.kernel_launches[KT_FRONTEND])
-    fe_flops = FE_FLOPS_PER_SAMPLE[S] * block * nrx
-    achieved_tf = fe_flops / (fe_ms * 1e-3) / 1e12 if fe_ms > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_frontend.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    dt, st = timed_leg(eng, ptrs, block, a.steps, a.warmup, barrier, (KT_FRONTEND,))
+    dt = max_over_ranks(dt, torch.device("cuda", local))
+    gather = gather_outputs(eng, nrx) if world > 1 else None
+
     value = a.steps * block * world / dt / 1e6
+    step_ms = dt / a.steps * 1e3
     res = {
         "metric": "input Msamples/s processed (whole node) at %d receivers per GPU" % nrx,
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if a.fp32 else "f64", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: %d %s receivers per GPU on a %.3f Msps complex-double stream, "
                                "mixer + cascaded decimating FIRs + demod + AGC" % (nrx, "SSB" if a.mix == "ssb" else "mixed SSB/AM/FM", fs / 1e6),
                    "block_samples": block, "receivers_total": total_rx, "sample_rate": fs, "sharding": "receivers"},
         "realtime_factor": value * 1e6 / world / fs,
         "receiver_msamples_per_s": value * nrx,
-        # "mfma": the compute roof.  The kernel is FP64 FMA work issued on the vector pipe; on MI355X the dense FP64
-        # MFMA peak and the FP64 vector peak are the same 78.6 TFLOP/s, so one number prices both.
-        "roofline": {"kernel": "k_frontend_wave<S=%d> (mixer + %d fused half-band decimators)" % (S, S),
-                     "bound": "mfma", "pipe": "fp64 vector FMA", "achieved": achieved_tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved_tf / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
-                     "avg_launch_ms": fe_ms, "launches": int(st.kernel_launches[KT_FRONTEND]),
-                     "algorithmic_flop_per_launch": fe_flops,
-                     "hbm": {"achieved": (16.0 * block + 16.0 * (block >> S) * nrx) / (fe_ms * 1e-3) / 1e9 if fe_ms > 0 else 0.0,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s"},
-                     "share_of_step": fe_ms / (dt / a.steps * 1e3) if dt > 0 else None},
+        "roofline": frontend_roofline(st, fs, block, nrx, step_ms, a.fp32, "r02_pmc_frontend_c2.json"),
     }
-    if gather_ms is not None:
-        res["gather_ms"] = gather_ms
+    if gather is not None:
+        res["gather"] = gather
+    eng.close()
+
+    # ---- the north-star slice: configs[3] per GPU ----
+    if not a.no_config4 and block >= (1 << 20):
+        fs4, nrx4 = 61440000, 128
+        t4 = tune_offsets(nrx4 * world, fs4)
+        m4 = mode_mix(nrx4 * world, "mixed")
+        lo4, hi4 = receiver_slice(nrx4 * world, world, rank)
+        eng4 = make_engine(fs4, nrx4, block, local, t4[lo4:hi4], m4[lo4:hi4], fp32=a.fp32)
+        k4 = min(a.steps, 100)
+        dt4, st4 = timed_leg(eng4, ptrs, block, k4, min(a.warmup, 10), barrier, (KT_FRONTEND,))
+        dt4 = max_over_ranks(dt4, torch.device("cuda", local))
+        v4 = k4 * block * world / dt4 / 1e6
+        leg = {"workload": "per-GPU share of BASELINE configs[3]: %d mixed SSB/AM/FM receivers per GPU at 61.44 Msps, "
+                           "2^20-sample blocks, AGC" % nrx4,
+               "value": v4, "unit": "Msamples/s", "steps": k4, "ms_per_step": dt4 / k4 * 1e3, "n_gpus": world,
+               "receivers_total": nrx4 * world, "realtime_factor": v4 * 1e6 / world / fs4,
+               "roofline": frontend_roofline(st4, fs4, block, nrx4, dt4 / k4 * 1e3, a.fp32, "r02_pmc_frontend_c4.json")}
+        if world > 1:
+            leg["gather"] = gather_outputs(eng4, nrx4)
+        eng4.close()
+        res["config4_slice"] = leg
+
+    with_cpu = rank == 0 and not a.no_cpu_baseline and world == 1
     if rank == 0 and not a.no_spectrum:
-        sp = spectrum_leg(local, ptrs, block)
+        sp = spectrum_leg(local, ptrs, block, with_cpu)
         if sp is not None:
             res["spectrum"] = sp
-    if rank == 0 and not a.no_cpu_baseline and world == 1:
+    if rank == 0 and not a.no_config1 and world == 1:
+        res["config1"] = config1_leg(local, with_cpu)
+    if with_cpu:
         res["cpu_baseline"] = cpu_baseline(fs, modes, tunes, a.cpu_samples, 1002)
-    eng.close()
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

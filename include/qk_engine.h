@@ -40,7 +40,8 @@ typedef struct qk_config {
     int fft_size;          /* display FFT size (any, e.g. data_width * fft_mult, quisk.py:3858-3890; powers of two run the
                               direct transform) or 0 for no spectrum (record_app, quisk.c:5054) */
     int data_width;        /* graph points returned by qk_get_graph (record_app, quisk.c:5054) */
-    int reserved[8];       /* [0] = largest receive-filter length accepted by qk_set_filters (0 = 1024); rest zero */
+    int reserved[8];       /* [0] = largest receive-filter length accepted by qk_set_filters (0 = 1024);
+                              [1] = 1: fp32 mode (BASELINE configs[4]; the reference computes in double); rest zero */
 } qk_config;
 
 /* record_app (quisk.c:5048-5113): allocates the FFT buffers/window and initialises every filter state

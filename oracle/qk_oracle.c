@@ -401,6 +401,24 @@ void qko_agc_process(qko_agc *a, qko_cd *x, int n, int is_cpx, int playback_rate
     }
 }
 
+/* Test aid (no counterpart in the reference): process_agc sample by sample, recording after each sample the gain in
+ * force for the NEXT sample and the discrete state (is_clipping, index_start), so that a test can say where two runs of
+ * the state machine part company.  The first call of a fresh state only initialises, as qko_agc_process does. */
+void qko_agc_trace(qko_agc *a, qko_cd *x, int n, int is_cpx, int playback_rate, double release_gain, double release_time,
+                   int fm_mode, double *gain_out, int *clip_out, int *istart_out)
+{
+    int i;
+    if (!a->buf_size) {
+        qko_agc_process(a, x, n, is_cpx, playback_rate, release_gain, release_time, fm_mode);
+        for (i = 0; i < n; i++) { gain_out[i] = a->gain; clip_out[i] = 0; istart_out[i] = 0; }
+        return;
+    }
+    for (i = 0; i < n; i++) {
+        qko_agc_process(a, x + i, 1, is_cpx, playback_rate, release_gain, release_time, fm_mode);
+        gain_out[i] = a->gain; clip_out[i] = a->is_clipping; istart_out[i] = a->index_start;
+    }
+}
+
 void qko_fracdecim_init(qko_fracstate *s) { memset(s, 0, sizeof *s); s->dindex = 1; }
 
 int qko_fracdecim(qko_fracstate *s, qko_cd *x, int n, double fdecim)

@@ -107,6 +107,9 @@ void qko_agc_free(qko_agc *a);
  * fm_mode is (rxMode == FM || rxMode == DGT_FM), quisk.c:2088. */
 void qko_agc_process(qko_agc *a, qko_cd *x, int n, int is_cpx, int playback_rate,
                      double release_gain, double release_time, int fm_mode);
+/* test aid: the same, one sample at a time, with the state after every sample */
+void qko_agc_trace(qko_agc *a, qko_cd *x, int n, int is_cpx, int playback_rate, double release_gain, double release_time,
+                   int fm_mode, double *gain_out, int *clip_out, int *istart_out);
 
 typedef struct { double dindex; qko_cd c0, c1, c2, c3; } qko_fracstate; /* statics at quisk.c:575-576 */
 void qko_fracdecim_init(qko_fracstate *s);

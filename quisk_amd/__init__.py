@@ -4,4 +4,4 @@ The compute path is the HIP library `libqkengine.so` (C ABI in include/qk_engine
 the thin host-side mirror used by tests, bench.py and Python callers.  There is no CPU fallback.
 """
 from .engine import Engine, QkError, lib, plan_decimation, get_filter_rate, decim_rate  # noqa: F401
-from .rxfilters import make_filter_coef, filter_center, MODES, MODE_INDEX  # noqa: F401
+from .rxfilters import make_filter_coef, filter_center, rx_filter, MODES, MODE_INDEX, DEFAULT_BW  # noqa: F401

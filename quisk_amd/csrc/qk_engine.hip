@@ -107,6 +107,8 @@ struct qk_engine {
     hipEvent_t ev_read[2] = {nullptr, nullptr};        // the chains have finished reading front-stream twin q
     bool read_pending[2] = {false, false};
     int fe_blocks = 0;                                 // blocks in which the front end produced output (twin parity)
+    long long pipe_blocks = 0;                         // blocks run by the receivers' pipeline: selects every ping-pong set (events, gains,
+                                                       // squelch flags).  Not stats.blocks, which qk_reset_stats zeroes between blocks.
     bool agc_pending = false;
     int nrx = 0, S = 0, tap_cap = DEFAULT_TAP_CAP;
     int fe_rate = 0, decim_srate = 0;
@@ -139,6 +141,7 @@ struct qk_engine {
     double squelch_level = -999.0; int kill_audio = 0; double *d_sq_state = nullptr, *d_sq_partial = nullptr; int *d_sq_flag = nullptr, sq_pstride = 0;
     AgcState *d_agc = nullptr; double *d_gains = nullptr, *d_agc_mag = nullptr; int gain_stride = 0;   // d_agc_mag: [rx][gain_stride] cabs of complex play streams
     int *d_agc_started = nullptr; std::vector<char> agc_started;    // per receiver: has process_agc run once?
+    int *h_agc_abort = nullptr, *d_agc_abort = nullptr;             // pinned word k_agc_gain sets when a hand-over timed out
     double agc_release_time = 1.0;
     // input conditioning (DCremove, sound.c:165-230; spectrum inversion, quisk.c:2315-2320)
     int dc_bw = 0, invert = 0;
@@ -515,6 +518,43 @@ static int upload_members(qk_engine *e)
     return QK_OK;
 }
 
+// A receiver moves from chain class `from` to class `to` (set_rx_mode, or DGT-U/L crossing DGT_NARROW_FREQ in set_filters).
+// The reference keeps ONE AGC delay ring per bank across mode changes (Agc1, quisk.c:2181), so the 15 ms of audio in the
+// old class's play stream become the history of the new class's play stream; every other history of the receiver in the
+// new class is cleared (the reference's filter objects of the new mode hold whatever that mode last left there: stale
+// audio from before the switch, which nobody should want reproduced; DESIGN.md "Known deviations").  All streams idle.
+static int migrate_receiver(qk_engine *e, int rx, int from, int to)
+{
+    Chain &n = e->cls_chain[to];
+    if (!n.built) return QK_OK;
+    for (auto &s : n.streams)
+        HIPCHECK(hipMemsetAsync(s.d + (long long)rx * s.rx_stride(), 0, sizeof(double) * s.rx_stride(), e->stream));
+    Stream &np = n.streams[n.play];
+    HIPCHECK(hipMemsetAsync(n.play_alt + (long long)rx * np.rx_stride(), 0, sizeof(double) * np.rx_stride(), e->stream));
+    for (auto &st : n.stages)
+        if (st.iir_state) HIPCHECK(hipMemsetAsync(st.iir_state + 2 * rx, 0, 2 * sizeof(double), e->stream));
+    if (to == CL_FM) {      // fm_1 = 10 (quisk.c:1763), as at creation
+        Stream &f = n.streams[n.stages[0].out];
+        const double ten = 10.0;
+        HIPCHECK(hipMemcpyAsync(f.d + (long long)rx * f.rx_stride() + f.hist - 1, &ten, sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+    }
+    Chain &o = e->cls_chain[from];
+    if (from != to && o.built && e->agc_started[rx]) {
+        Stream &op = o.streams[o.play];
+        const int h = std::min(op.hist, np.hist);
+        for (int pl = 0; pl < np.planes; pl++) {
+            const int spl = pl < op.planes ? pl : 0;        // mono audio is both channels
+            const double *src = o.play_alt + (long long)rx * op.rx_stride() + (long long)spl * (op.hist + op.cap) + (op.hist - h);
+            for (double *base : {np.d, n.play_alt})
+                HIPCHECK(hipMemcpyAsync(base + (long long)rx * np.rx_stride() + (long long)pl * (np.hist + np.cap) + (np.hist - h), src,
+                                        sizeof(double) * h, hipMemcpyDeviceToDevice, e->stream));
+        }
+    }
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return QK_OK;
+}
+
 static int upload_tune(qk_engine *e, int rx)
 {
     double pre, pim;
@@ -614,6 +654,9 @@ static int init_receivers(qk_engine *e)
     HIPCHECK(hipMalloc(&e->d_agc_started, nrx * sizeof(int)));
     HIPCHECK(hipMemset(e->d_agc_started, 0, nrx * sizeof(int)));
     e->agc_started.assign(nrx, 0);
+    HIPCHECK(hipHostMalloc(&e->h_agc_abort, sizeof(int), hipHostMallocMapped));
+    *e->h_agc_abort = 0;
+    HIPCHECK(hipHostGetDevicePointer((void **)&e->d_agc_abort, e->h_agc_abort, 0));
     // output: the audio of one block at the play rate
     const long long per_block = (long long)cfg.max_block * cfg.playback_rate / cfg.sample_rate + 64;
     if (per_block > (1LL << 26)) return fail(QK_ERANGE, "max_block gives more than 2^26 audio samples per block (k_agc_gain tile index)");
@@ -647,6 +690,13 @@ static int init_receivers(qk_engine *e)
         const size_t bytes = (size_t)e->nrx * e->front.streams[0].rx_stride() * sizeof(double);
         HIPCHECK(hipMalloc(&e->front.front_alt, bytes));
         HIPCHECK(hipMemsetAsync(e->front.front_alt, 0, bytes, e->stream));
+    }
+    {   // the band-pass kernel stages FT_NTH * FT_R + taps doubles in dynamic LDS: above 64 KiB the launch needs the attribute
+        const size_t lds = sizeof(double) * (FT_NTH * FT_R + e->tap_cap + FT_QB);
+        if (lds > 160 * 1024) return fail(QK_ERANGE, "receive-filter capacity needs more LDS than a CU has");
+        if (lds > 48 * 1024)
+            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rxf_tiled<FT_NTH, FT_R>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     rc = upload_members(e);
     if (rc != QK_OK) return rc;
@@ -1130,7 +1180,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
                 Timer tm(e, st.timer);
                 hipLaunchKernelGGL(k_fm_disc, grid1(n_in, 1, nlist), dim3(256), 0, e->stream, a);
                 // the FM squelch measures the filtered samples (quisk.c:1892, 1911-1920)
-                SquelchArgs q{e->d_sq_partial, e->sq_pstride, np, n_in, d_list, e->d_sq_state, e->d_sq_flag + (e->stats.blocks & 1) * e->nrx,
+                SquelchArgs q{e->d_sq_partial, e->sq_pstride, np, n_in, d_list, e->d_sq_state, e->d_sq_flag + (e->pipe_blocks & 1) * e->nrx,
                               e->squelch_level};
                 hipLaunchKernelGGL(k_fm_squelch, dim3(nlist), dim3(256), 0, e->stream, q);
             }
@@ -1349,7 +1399,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         F.front_last_n = f0.n;
     }
     {
-        hipEvent_t evf = (e->stats.blocks & 1) ? e->ev_fe2 : e->ev_fe;
+        hipEvent_t evf = (e->pipe_blocks & 1) ? e->ev_fe2 : e->ev_fe;
         HIPCHECK(hipEventRecord(evf, e->fe_stream));
         HIPCHECK(hipStreamWaitEvent(e->stream, evf, 0));
     }
@@ -1374,7 +1424,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     }
     // ---- AGC on its own stream: serial in time per receiver (one wave each), so it runs beside the next
     //      block's front end and FIR chain instead of in front of them ----
-    const int par = (int)(e->stats.blocks & 1);
+    const int par = (int)(e->pipe_blocks & 1);
     HIPCHECK(hipEventRecord(e->ev_chain, e->stream));
     HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_chain, 0));
     if (fe_writes) {
@@ -1406,7 +1456,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             a.time_release = 1.0 - exp(-1.0 / rate / e->agc_release_time);       // quisk.c:2045
             a.release_gain = e->d_release_gain; a.mode = e->d_mode; a.state = e->d_agc;
             a.out = e->d_out; a.out_stride = (long long)e->out_stride;
-            a.started = e->d_agc_started;
+            a.started = e->d_agc_started; a.abort_flag = e->d_agc_abort;
             a.mute = e->d_sq_flag + par * e->nrx; a.kill = e->kill_audio;
             Timer tm(e, QK_KT_AGC, e->agc_stream);
             if (any_cpx) hipLaunchKernelGGL(k_agc_cabs, grid1(m_max, 1, e->nrx), dim3(256), 0, e->agc_stream, a);
@@ -1471,6 +1521,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     HIPCHECK(hipGetLastError());
     e->stats.samples_in += n;
     e->stats.blocks += 1;
+    e->pipe_blocks += 1;
     return QK_OK;
 }
 
@@ -1493,6 +1544,8 @@ int qk_create(qk_engine **out, const qk_config *cfg)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(QK_EHIP, "no HIP device: the engine has no CPU path");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(QK_EINVAL, "bad device ordinal");
+    if (cfg->reserved[1] != 0 && cfg->reserved[1] != 1) return fail(QK_EINVAL, "qk_config.reserved[1]: 0 = fp64, 1 = fp32 mode");
+    if (cfg->reserved[1] == 1) return fail(QK_EUNSUPPORTED, "fp32 mode is not built yet");
     qk_engine *e = new (std::nothrow) qk_engine();
     if (!e) return fail(QK_ENOMEM, "out of host memory");
     e->cfg = *cfg;
@@ -1532,6 +1585,7 @@ void qk_destroy(qk_engine *e)
     if (e->ev_gain) hipEventDestroy(e->ev_gain);
     if (e->d_gains2) hipFree(e->d_gains2);
     if (e->d_agc_started2) hipFree(e->d_agc_started2);
+    if (e->h_agc_abort) hipHostFree(e->h_agc_abort);
     if (e->ev_chain) hipEventDestroy(e->ev_chain);
     for (auto &ev : e->ev_agc) if (ev) hipEventDestroy(ev);
     if (e->ev_fe) hipEventDestroy(e->ev_fe);
@@ -1550,6 +1604,9 @@ void qk_destroy(qk_engine *e)
                          HIPCHECK(hipStreamSynchronize((e)->agc_stream)); \
                          if ((e)->apply_stream) HIPCHECK(hipStreamSynchronize((e)->apply_stream)); } while (0)
 #define RX_CHECK(e, rx) if ((rx) < 0 || (rx) >= (e)->nrx) return fail(QK_ERANGE, "receiver index out of range")
+// after a synchronisation: a hand-over inside k_agc_gain that ran out of polls left NaN gains behind (qk_kernels.h, AGC_SPIN_LIMIT)
+#define AGC_ABORT_CHECK(e) do { if ((e)->h_agc_abort && *(e)->h_agc_abort) \
+        return fail(QK_EHIP, "AGC kernel: a hand-over between its waves timed out; the audio of this block is not valid"); } while (0)
 
 int qk_set_tune(qk_engine *e, int rx, int tune_hz)
 {
@@ -1579,7 +1636,12 @@ int qk_set_mode(qk_engine *e, int rx, int mode)
     HIPCHECK(hipMemcpy(e->d_mode + rx, &mode, sizeof(int), hipMemcpyHostToDevice));
     { int rcn = upload_ntaps(e, rx); if (rcn != QK_OK) return rcn; }
     for (int b = 0; b < 2; b++) HIPCHECK(hipMemset(e->d_sq_flag + b * e->nrx + rx, 0, sizeof(int)));     // squelch_active = 0, quisk.c:1777
-    if (e->cls[rx] != cl) { e->cls[rx] = cl; return upload_members(e); }
+    if (e->cls[rx] != cl) {
+        const int from = e->cls[rx];
+        e->cls[rx] = cl;
+        int rcm = upload_members(e);
+        return rcm != QK_OK ? rcm : migrate_receiver(e, rx, from, cl);
+    }
     return QK_OK;
 }
 
@@ -1602,7 +1664,12 @@ int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int
     e->ntaps[rx] = n; e->bandwidth[rx] = bandwidth; e->start_offset[rx] = start_offset;
     { int rcn = upload_ntaps(e, rx); if (rcn != QK_OK) return rcn; }
     const int cl = class_of_mode(e->mode[rx], bandwidth);      // DGT-U/L change chain with the bandwidth
-    if (cl >= 0 && cl != e->cls[rx]) { e->cls[rx] = cl; return upload_members(e); }
+    if (cl >= 0 && cl != e->cls[rx]) {
+        const int from = e->cls[rx];
+        e->cls[rx] = cl;
+        int rcm = upload_members(e);
+        return rcm != QK_OK ? rcm : migrate_receiver(e, rx, from, cl);
+    }
     return QK_OK;
 }
 
@@ -1636,7 +1703,7 @@ int qk_squelch_active(qk_engine *e, int rx)
     ENGINE_ENTER(e); RX_CHECK(e, rx);
     SYNC_ALL(e);
     int f = 0;
-    HIPCHECK(hipMemcpy(&f, e->d_sq_flag + ((e->stats.blocks + 1) & 1) * e->nrx + rx, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(&f, e->d_sq_flag + ((e->pipe_blocks + 1) & 1) * e->nrx + rx, sizeof(int), hipMemcpyDeviceToHost));
     return f;
 }
 
@@ -1746,6 +1813,7 @@ int qk_sync(qk_engine *e)
 {
     ENGINE_ENTER(e);
     SYNC_ALL(e);
+    AGC_ABORT_CHECK(e);
     return QK_OK;
 }
 
@@ -1767,6 +1835,7 @@ int qk_pull_audio(qk_engine *e, int rx, double *dst, int cap)
                                 hipMemcpyDeviceToHost, e->stream));
     }
     SYNC_ALL(e);
+    AGC_ABORT_CHECK(e);
     return m;
 }
 
@@ -1784,6 +1853,7 @@ int qk_pull_audio_all(qk_engine *e, double *dst, size_t stride, int *counts)
     HIPCHECK(hipMemcpy2DAsync(dst, stride * sizeof(double2), e->d_out, e->out_stride * sizeof(double2),
                               std::min(stride, e->out_stride) * sizeof(double2), e->nrx, hipMemcpyDeviceToHost, e->stream));
     SYNC_ALL(e);
+    AGC_ABORT_CHECK(e);
     return QK_OK;
 }
 
@@ -1971,6 +2041,7 @@ int qk_export_audio_device(qk_engine *e, double *dst_dev, size_t dst_stride)
         HIPCHECK(hipMemcpy2DAsync(dst_dev, dst_stride * sizeof(double2), e->d_out, e->out_stride * sizeof(double2),
                                   w * sizeof(double2), e->nrx, hipMemcpyDeviceToDevice, e->stream));
     SYNC_ALL(e);
+    AGC_ABORT_CHECK(e);
     return QK_OK;
 }
 

@@ -801,6 +801,7 @@ struct AgcArgs {
     double2 *out; long long out_stride;   // [rx][out_stride] interleaved stereo
     const int *started;        // [rx] 0 until the receiver's first call: the reference then only initialises
                                // and returns the block untouched (quisk.c:2033-2050)
+    int *abort_flag;           // host-visible word, set when a hand-over of k_agc_gain timed out (the gains are then NaN)
 };
 
 // cabs for the complex AGC.  The reference's cabs is the C library's hypot; the oracle runs against glibc 2.35, whose
@@ -1254,7 +1255,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
             if (!dead) tile(k);
             if (lane == 0) poke(&wstat, tag_of(gen, k + 1));
         }
-        if (dead) { poke(&aborted, 1); s.gain = __builtin_nan(""); }
+        if (dead) { poke(&aborted, 1); s.gain = __builtin_nan(""); if (lane == 0 && a.abort_flag) *a.abort_flag = 1; }
         if (lane == 0) { poke(&wstat, tag_of(gen, T)); a.state[rx] = s; }
     } else {
         // ---------------- the fetcher ----------------

@@ -47,4 +47,4 @@ def make_iq(n, fs, tunes, modes, seed, start=0, chunk=1 << 18):
     return out
 
 
-DEFAULT_BW = {0: 500, 1: 500, 2: 2800, 3: 2800, 4: 8000, 5: 16000, 7: 3200, 8: 3200, 9: 6000, 13: 16000}   # default filter widths, quisk.py:3579-3588
+from .rxfilters import DEFAULT_BW  # noqa: E402,F401  (default filter widths, quisk.py:3579-3588)

@@ -122,6 +122,7 @@ def oracle():
     L.qko_agc_init.argtypes = [P(OAgc), C.c_double, C.c_int]
     L.qko_agc_free.argtypes = [P(OAgc)]
     L.qko_agc_process.argtypes = [P(OAgc), cdp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
+    L.qko_agc_trace.argtypes = [P(OAgc), cdp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, ddp, idp, idp]
     L.qko_fracdecim_init.argtypes = [P(OFrac)]
     L.qko_fracdecim.argtypes = [P(OFrac), cdp, C.c_int, C.c_double]
     L.qko_fft.argtypes = [cdp, C.c_int]

@@ -190,8 +190,9 @@ def _bursty_iq(n, fs, tunes, seed):
 ])
 def test_agc_under_keyed_signals(agc_gain, playback, sizes):
     """The AGC kernel (runner / walker / fetcher waves, restarts in the middle of tiles) bit for bit against the
-    oracle's process_agc on signals that keep it switching between its two states.  End to end the bound is loose on
-    purpose: what is asserted is the exactness of the AGC on identical input and the 1e-9 in front of it."""
+    oracle's process_agc on signals that keep it switching between its two states.  End to end: the measured statement
+    of tests/_rxsetup.py (errors above 1e-9 only inside divergence episodes that start at a discrete decision, are explained
+    by the gain difference, and close again)."""
     fs = 192000
     tunes, modes = [30000, -41000], [3, 4]
     x = _bursty_iq(sum(sizes), fs, tunes, 4242 + int(agc_gain))
@@ -203,7 +204,8 @@ def test_agc_under_keyed_signals(agc_gain, playback, sizes):
         pos += n
     passes = [eng.L.qk_debug_agc_passes(eng.h, r) for r in range(2)]
     pr.close()
-    pr.check(final_tol=1.0)
+    rep = pr.check()
+    print("agc end-to-end", rep)
     tiles = sum(-(-(n * playback // fs) // 64) for n in sizes)
     if agc_gain >= 5000:
         assert max(passes) > tiles      # events did occur: more speculation passes than tiles

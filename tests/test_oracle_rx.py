@@ -103,6 +103,38 @@ def test_agc_is_ill_conditioned():
     assert worst > 1e-9, worst
 
 
+def test_agc_deviation_report_on_perturbed_oracle():
+    """The measured end-to-end statement of tests/_rxsetup.py, exercised on the CPU: the "engine" is the oracle's own
+    process_agc fed inputs perturbed by 1e-13 relative (what the GPU path's different summation order amounts to).
+    Every output above 1e-9 must sit in a divergence episode that a discrete decision opened, be explained by the gain
+    difference, and the streams must re-converge; at least one trial does diverge (or the test proves nothing)."""
+    from _rxsetup import agc_deviation_report
+    L = B.oracle()
+    rng = np.random.default_rng(11)
+    n, blk = 48000 * 3, 4800
+    t = np.arange(n) / 48000.0
+    env = np.repeat(2.0 ** rng.uniform(16, 30, n // 2400) * (rng.random(n // 2400) < 0.6), 2400)   # keyed carrier
+    base = env * np.sin(2 * np.pi * 1000 * t) + 3e4 * rng.standard_normal(n)
+    seen, closed = 0, 0
+    for trial in range(5):
+        pert = base * (1 + 1e-13 * rng.standard_normal(n))
+        blocks, outs = [], []
+        for sig in (base, pert):
+            a = B.OAgc()
+            L.qko_agc_init(C.byref(a), 0.7, 0)
+            s = (sig + 1j * sig).astype(np.complex128)
+            blocks.append([sig[i:i + blk].copy() for i in range(0, n, blk)])
+            for i in range(0, n, blk):
+                b = np.ascontiguousarray(s[i:i + blk])
+                L.qko_agc_process(C.byref(a), b, len(b), 0, 48000, 5000.0, 1.0, 0)
+                s[i:i + blk] = b
+            outs.append(s)
+        rep = agc_deviation_report(blocks[0], blocks[1], outs[0], outs[1], 48000, 3, agc_gain=5000.0)
+        seen += rep["above_1e-9"]
+        closed += rep["closed_episodes"]
+    assert seen > 0 and closed > 0, (seen, closed)
+
+
 def test_graph_release_scaling():
     """A full-scale complex tone on a bin centre reads about 0 dB minus the Hann window's coherent gain (6.02 dB)."""
     N = 4096

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import _bind as B
-from _rxsetup import rx_filter, make_oracle_rx, rel_err, TOL_AGC
+from _rxsetup import rx_filter, make_oracle_rx, rel_err, TOL
 from quisk_amd import _quisk as QS
 from quisk_amd.synth import make_iq
 
@@ -62,7 +62,7 @@ def test_receive_path_through_the_module_interface():
         assert len(got) == len(want)
         if len(want):
             worst = max(worst, rel_err(got, want))
-    assert worst < TOL_AGC
+    assert worst < TOL         # a steady tone: the AGC's one start-up ramp ends alike in both (tests/_rxsetup.py, 3.)
     og.add_frames(x)
     import time
     time.sleep(0.01)
