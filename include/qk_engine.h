@@ -190,6 +190,19 @@ int quisk_cCplxSampleFilter(double *samples, int count, const double *coefs, int
 int quisk_ccfFilter(double *samples, int count, const double *cpx_coefs, int ntaps, int decim,
                     double *hist, int *phase);
 
+/* No counterpart in the reference.  For callers that cannot allocate: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  quisk_cCplxSampleFilter (above) with every buffer already in DEVICE memory:
+ * samples (count complex, filtered in place), coefs (ntaps doubles), hist (ntaps - 1 complex, updated); *phase is a
+ * host word.  The staging that an in-place FIR needs lives in a fixed array inside the library, QK_NOALLOC_MAX_SAMPLES
+ * complex samples (8 MiB on every GPU the library runs on, held until the process ends): a call whose
+ * (ntaps - 1 + count) + outputs exceeds it returns QK_ERANGE.  Calls no hipMalloc / hipFree or any allocating routine;
+ * the three kernels are queued on `hip_stream` (a hipStream_t; NULL = the default stream) and nothing waits for them.
+ * Every call on one GPU shares that GPU's staging array: calls that overlap in time on one GPU race; calls on one
+ * stream do not.  Returns the output count, like the reference's functions. */
+#define QK_NOALLOC_MAX_SAMPLES (1 << 19)
+int quisk_cCplxSampleFilter_noalloc(double *samples_dev, int count, const double *coefs_dev, int ntaps, int decim,
+                                    double *hist_dev, int *phase, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

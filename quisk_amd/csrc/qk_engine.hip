@@ -2100,6 +2100,58 @@ static int fir_dropin(double *samples, int count, const double *coefs, int ntaps
     return n_out;
 }
 
+// ---- the entry point that allocates nothing (include/qk_engine.h) ----
+// Staging for the in-place filter lives in a file-scope device array; each GPU holds its own copy at its own address,
+// looked up once per device (hipGetSymbolAddress) and used through that pointer only -- the array's name is a host-side
+// stand-in, not a device address.
+static __device__ __align__(256) double2 qk_na_scratch[QK_NOALLOC_MAX_SAMPLES];
+static std::mutex g_na_mu;
+static double2 *g_na_ptr[64] = {nullptr};
+static int noalloc_scratch(double2 **out)
+{
+    int dev = -1;
+    HIPCHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(QK_ERANGE, "device ordinal beyond the scratch table");
+    std::lock_guard<std::mutex> lk(g_na_mu);
+    if (!g_na_ptr[dev]) {
+        double2 *p = nullptr;
+        HIPCHECK(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(qk_na_scratch)));
+        if (!p) return fail(QK_EHIP, "hipGetSymbolAddress returned a null scratch address");
+        g_na_ptr[dev] = p;
+    }
+    *out = g_na_ptr[dev];
+    return QK_OK;
+}
+
+int quisk_cCplxSampleFilter_noalloc(double *samples_dev, int count, const double *coefs_dev, int ntaps, int decim,
+                                    double *hist_dev, int *phase, void *hip_stream)
+{
+    if (!samples_dev || !coefs_dev || !hist_dev || !phase || count < 0 || ntaps < 1 || decim < 1 || *phase < 0 || *phase >= decim)
+        return fail(QK_EINVAL, "bad FIR arguments");
+    const int n_out = (*phase + count) / decim, first = decim - 1 - *phase;
+    const long long nh = (long long)ntaps - 1, ntot = nh + count;
+    if (ntot + n_out > (long long)QK_NOALLOC_MAX_SAMPLES)
+        return fail(QK_ERANGE, "quisk_cCplxSampleFilter_noalloc: (ntaps - 1 + count) + outputs exceeds the fixed scratch of "
+                               "QK_NOALLOC_MAX_SAMPLES complex samples; split the block");
+    double2 *scratch = nullptr;
+    int rc = noalloc_scratch(&scratch);
+    if (rc != QK_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    double2 *cat = scratch, *y = scratch + ntot;
+    if (ntot > 0)
+        hipLaunchKernelGGL(k_na_gather, dim3((unsigned)((ntot + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const double2 *>(hist_dev),
+                           reinterpret_cast<const double2 *>(samples_dev), cat, (int)nh, count);
+    if (n_out > 0)
+        hipLaunchKernelGGL(k_cfir_interleaved, dim3((n_out + 255) / 256), dim3(256), 0, st, cat, y, coefs_dev, ntaps, decim, first, n_out, 0);
+    const long long m = std::max<long long>(n_out, nh);
+    if (m > 0)
+        hipLaunchKernelGGL(k_na_scatter, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, cat, y, reinterpret_cast<double2 *>(samples_dev),
+                           reinterpret_cast<double2 *>(hist_dev), (int)nh, count, n_out);
+    HIPCHECK(hipGetLastError());
+    *phase = (*phase + count) % decim;
+    return n_out;
+}
+
 long long qk_debug_agc_passes(qk_engine *e, int rx)
 {   /* statistics: speculation passes the AGC kernel has run for this receiver (debug) */
     if (!e || rx < 0 || rx >= e->nrx) return -1;

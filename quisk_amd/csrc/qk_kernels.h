@@ -1682,3 +1682,17 @@ __global__ __launch_bounds__(256) void k_cfir_interleaved(const double2 *x, doub
     }
     y[j] = make_double2(ar, ai);
 }
+
+// The allocation-free drop-in (quisk_cCplxSampleFilter_noalloc): the filter runs in place, so inputs are staged.  Scratch
+// layout: cat[nh + count] = history followed by the block (what k_cfir_interleaved reads), then y[n_out].
+__global__ __launch_bounds__(256) void k_na_gather(const double2 *hist, const double2 *samples, double2 *cat, int nh, int count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nh + count) cat[i] = i < nh ? hist[i] : samples[i - nh];
+}
+__global__ __launch_bounds__(256) void k_na_scatter(const double2 *cat, const double2 *y, double2 *samples, double2 *hist, int nh, int count, int n_out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_out) samples[i] = y[i];
+    if (i < nh) hist[i] = cat[count + i];           // the last nh samples of (history + block)
+}

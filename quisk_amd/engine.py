@@ -86,6 +86,7 @@ def lib():
     L.qk_debug_agc_passes.restype = C.c_longlong
     L.quisk_cCplxSampleFilter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip]
     L.quisk_ccfFilter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip]
+    L.quisk_cCplxSampleFilter_noalloc.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip, vp]
     _lib = L
     return L
 
