@@ -33,6 +33,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 namespace {
 
 constexpr int DEFAULT_TAP_CAP = 1024;
+constexpr int FFT_BATCH = 8;          // display-spectrum frames per four-step launch
 constexpr int EV_POOL = 2048;
 
 enum StageKind { ST_FIR, ST_INTERP, ST_HBINT, ST_RESAMP, ST_RXF, ST_FMDISC, ST_IIR, ST_FRAC };
@@ -991,11 +992,12 @@ static int init_spectrum(qk_engine *e)
         if (rcb != QK_OK) return rcb;
     }
     HIPCHECK(hipMalloc(&e->d_fft_stage, sizeof(double2) * N));
-    if (e->fftN1 > 1 || e->blue) HIPCHECK(hipMalloc(&e->d_fft_Y, sizeof(double2) * N));
+    if (e->blue) HIPCHECK(hipMalloc(&e->d_fft_Y, sizeof(double2) * N));
+    else if (e->fftN1 > 1) HIPCHECK(hipMalloc(&e->d_fft_Y, sizeof(double2) * N * FFT_BATCH));      // Y of up to FFT_BATCH frames per launch
     HIPCHECK(hipMalloc(&e->d_fft_avg, sizeof(double) * N));
     HIPCHECK(hipMemset(e->d_fft_avg, 0, sizeof(double) * N));
     e->band_cap = N / 2 + 2;
-    HIPCHECK(hipMalloc(&e->d_band, sizeof(double) * e->band_cap));
+    HIPCHECK(hipMalloc(&e->d_band, sizeof(double) * e->band_cap * FFT_BATCH));
     HIPCHECK(hipMalloc(&e->d_meter, sizeof(double)));
     HIPCHECK(hipMemset(e->d_meter, 0, sizeof(double)));
     HIPCHECK(hipMalloc(&e->d_graph, sizeof(double) * W));
@@ -1004,13 +1006,15 @@ static int init_spectrum(qk_engine *e)
     return QK_OK;
 }
 
-// one complete frame of fft_size samples at `frame` (device): window, FFT, S-meter bins, magnitude average
-static void fft_frame(qk_engine *e, const double2 *frame)
+// `frames` complete, consecutive frames of fft_size samples at `frame` (device): window, FFT, S-meter bins, magnitude average.
+// Only the four-step transform takes more than one frame per launch (frames <= FFT_BATCH).
+static void fft_frames(qk_engine *e, const double2 *frame, int frames)
 {
     const int N = e->fftN;
     FftArgs a{};
     a.x = frame; a.window = e->d_window; a.tw4096 = e->d_tw4096; a.tw_lo = e->d_tw_lo; a.tw_hi = e->d_tw_hi;
     a.Y = e->d_fft_Y; a.avg = e->d_fft_avg; a.band = e->d_band; a.N = N; a.N1 = e->fftN1;
+    a.frames = frames; a.band_stride = e->band_cap; a.accumulate = e->fft_count > 0;
     // S-meter pass band of receiver 0 (quisk.c:4659-4667)
     const int fs = e->cfg.sample_rate;
     const int bw = e->nrx > 0 ? e->bandwidth[0] : 0;
@@ -1026,8 +1030,8 @@ static void fft_frame(qk_engine *e, const double2 *frame)
         blue_run(e, e->blue, e->fe_stream, frame, nullptr, e->d_fft_Y);
         hipLaunchKernelGGL(k_graph_accum, dim3((N + 255) / 256), dim3(256), 0, e->fe_stream, e->d_fft_Y, a);
     } else if (e->fftN1 > 1) {
-        hipLaunchKernelGGL(k_fft_cols, dim3(e->fftN1), dim3(FFT_BIG_THREADS), 0, e->fe_stream, a);
-        hipLaunchKernelGGL(k_fft_rows, dim3(e->fftN1), dim3(FFT_BIG_THREADS), 0, e->fe_stream, a);
+        hipLaunchKernelGGL(k_fft_cols, dim3(e->fftN1, frames), dim3(FT16_THREADS), 0, e->fe_stream, a);
+        hipLaunchKernelGGL(k_fft_rows, dim3(e->fftN1), dim3(FT16_THREADS), 0, e->fe_stream, a);
     } else {
         switch (N) {
         case 64: hipLaunchKernelGGL(k_fft_small<64>, dim3(1), dim3(FFT_THREADS), 0, e->fe_stream, a); break;
@@ -1040,28 +1044,30 @@ static void fft_frame(qk_engine *e, const double2 *frame)
         }
     }
     if (meter_on)
-        hipLaunchKernelGGL(k_meter_accum, dim3(1), dim3(64), 0, e->fe_stream, e->d_band, nw, d2 - nw, e->d_meter);
-    e->fft_count++;
-    e->stats.fft_frames++;
+        hipLaunchKernelGGL(k_meter_accum, dim3(1), dim3(64), 0, e->fe_stream, e->d_band, nw, d2 - nw, e->d_meter, frames, e->band_cap);
+    e->fft_count += frames;
+    e->stats.fft_frames += frames;
 }
 
 // FFT staging (quisk.c:2324-2348): consecutive, non-overlapping frames of the PRE-mixer samples.  The reference
 // queues at most four frames for the GUI thread and drops the rest (fft_error); here every frame is
-// transformed as soon as it is complete.
+// transformed as soon as it is complete (several at once when a block holds several).
 static int feed_spectrum(qk_engine *e, const double2 *x, int n)
 {
     const int N = e->fftN;
     int pos = 0;
     while (pos < n) {
-        if (e->fft_fill == 0 && n - pos >= N) {         // whole frame straight from the input block
-            fft_frame(e, x + pos);
-            pos += N;
+        if (e->fft_fill == 0 && n - pos >= N) {         // whole frames straight from the input block
+            const int batch = e->fftN1 > 1 ? FFT_BATCH : 1;
+            const int f = std::min(batch, (n - pos) / N);
+            fft_frames(e, x + pos, f);
+            pos += f * N;
             continue;
         }
         const int take = std::min(N - e->fft_fill, n - pos);
         HIPCHECK(hipMemcpyAsync(e->d_fft_stage + e->fft_fill, x + pos, sizeof(double2) * take, hipMemcpyDeviceToDevice, e->fe_stream));
         e->fft_fill += take; pos += take;
-        if (e->fft_fill == N) { fft_frame(e, e->d_fft_stage); e->fft_fill = 0; }
+        if (e->fft_fill == N) { fft_frames(e, e->d_fft_stage, 1); e->fft_fill = 0; }
     }
     return QK_OK;
 }
@@ -1087,7 +1093,8 @@ static int release_graph(qk_engine *e, double zoom, double deltaf, double *out, 
     double meter = 0;
     HIPCHECK(hipMemcpyAsync(out, e->d_graph, sizeof(double) * W, hipMemcpyDeviceToHost, e->fe_stream));
     HIPCHECK(hipMemcpyAsync(&meter, e->d_meter, sizeof(double), hipMemcpyDeviceToHost, e->fe_stream));
-    HIPCHECK(hipMemsetAsync(e->d_fft_avg, 0, sizeof(double) * N, e->fe_stream));
+    if (e->fftN1 <= 1)      // (the four-step pass B overwrites the average when it starts a new one: no 8 N bytes of zeros)
+        HIPCHECK(hipMemsetAsync(e->d_fft_avg, 0, sizeof(double) * N, e->fe_stream));
     HIPCHECK(hipMemsetAsync(e->d_meter, 0, sizeof(double), e->fe_stream));
     HIPCHECK(hipStreamSynchronize(e->fe_stream));
     const double scale = 1.0 / 2147483647.0 / N;                    // quisk.c:4728-4737

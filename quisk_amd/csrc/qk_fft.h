@@ -106,6 +106,8 @@ struct FftArgs {
     double *band;              // |X|^2 of the S-meter pass-band bins of this frame (quisk.c:4659-4680)
     int N, N1;
     int band_start, band_count;   // first bin (signed, relative to DC) and number of bins kept (whole + fractional)
+    int frames, band_stride;      // four-step passes: frames per launch (consecutive in x and Y), doubles between the frames' band arrays
+    int accumulate;               // four-step pass B: 0 = this launch starts a new average (write), 1 = add to it
 };
 
 // epilogue shared by the single-workgroup FFT and pass B: element e of the row is X[k1 + N1 e]
@@ -131,49 +133,202 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_small(FftArgs a)
     for (int e = threadIdx.x; e < TOTAL; e += FFT_THREADS) fft_epilogue(a, 0, e, buf[e]);
 }
 
-// pass A: blockIdx.x = column tile; TW = 4096 / N1 columns per tile
-__global__ __launch_bounds__(FFT_BIG_THREADS) void k_fft_cols(FftArgs a)
+// ------------------------------------------------------------------------------------------------
+// The 4096-element tile of the four-step passes: 256 lanes x 16 elements, radix-16 butterflies in registers.
+// A tile holds s interleaved sequences of length n (n s = 4096; element (p, q) at q + s p) and is transformed by
+// Stockham passes of radix 16 while n >= 16 and one last pass of radix n in {2, 4, 8}.  The first pass takes its
+// operands straight from global memory (`load`), the last one hands its results to `store`: a 4096-point row needs
+// two trips through LDS, a 256-point column tile one, a 16-point one none.  LDS indices are padded by one element
+// in sixteen, which makes the stride-16 stores of a radix-16 pass conflict-free (272 B apart instead of 256 B).
+// `slot` (0..15) is the lane's compile-time register slot of the element, for callers that keep per-element state.
+// ------------------------------------------------------------------------------------------------
+#define FT16_THREADS 256
+#define FT16_LDS (4096 + 256)
+// workgroup barrier that waits for the wave's LDS traffic only: __syncthreads() also drains the vector-memory queue, which
+// would make every pass wait for prefetched rows and for stores nobody reads
+#define FT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+__device__ __forceinline__ int ft16_pad(int i) { return i + (i >> 4); }
+__device__ __forceinline__ void ft_bfly2(double2 &a, double2 &b)
 {
-    __shared__ __attribute__((aligned(16))) double2 buf[4096];
-    const int N1 = a.N1, TW = 4096 / N1;
+    const double2 t = make_double2(a.x - b.x, a.y - b.y);
+    a = make_double2(a.x + b.x, a.y + b.y); b = t;
+}
+// forward 4-point DFT in place: (a, b, c, d) <- (y0, y1, y2, y3)
+__device__ __forceinline__ void ft_bfly4(double2 &a, double2 &b, double2 &c, double2 &d)
+{
+    const double2 apc = make_double2(a.x + c.x, a.y + c.y), amc = make_double2(a.x - c.x, a.y - c.y);
+    const double2 bpd = make_double2(b.x + d.x, b.y + d.y), bmd = make_double2(b.x - d.x, b.y - d.y);
+    a = make_double2(apc.x + bpd.x, apc.y + bpd.y);
+    c = make_double2(apc.x - bpd.x, apc.y - bpd.y);
+    b = make_double2(amc.x + bmd.y, amc.y - bmd.x);         // amc - i bmd
+    d = make_double2(amc.x - bmd.y, amc.y + bmd.x);         // amc + i bmd
+}
+#define FT_C8 0.92387953251128673848    /* cos(pi/8) */
+#define FT_S8 0.38268343236508978178    /* sin(pi/8) */
+#define FT_H  0.70710678118654752440    /* sqrt(1/2) */
+__device__ __forceinline__ double2 ft_mul_h(double2 v, double cr, double ci) { return make_double2(v.x * cr - v.y * ci, v.x * ci + v.y * cr); }
+// forward 16-point DFT of r[j], j = j0 + 4 j1; X[k] is left in r[(k >> 2) + 4 (k & 3)]
+__device__ __forceinline__ void ft_radix16(double2 (&r)[16])
+{
+#pragma unroll
+    for (int j0 = 0; j0 < 4; j0++) ft_bfly4(r[j0], r[j0 + 4], r[j0 + 8], r[j0 + 12]);     // r[j0 + 4 k1] = sum_j1 a W4^(j1 k1)
+    // twiddles W16^(j0 k1)
+    r[5] = ft_mul_h(r[5], FT_C8, -FT_S8);                   // 1
+    r[9] = ft_mul_h(r[9], FT_H, -FT_H);                     // 2
+    r[13] = ft_mul_h(r[13], FT_S8, -FT_C8);                 // 3
+    r[6] = ft_mul_h(r[6], FT_H, -FT_H);                     // 2
+    r[10] = make_double2(r[10].y, -r[10].x);                // 4: -i
+    r[14] = ft_mul_h(r[14], -FT_H, -FT_H);                  // 6
+    r[7] = ft_mul_h(r[7], FT_S8, -FT_C8);                   // 3
+    r[11] = ft_mul_h(r[11], -FT_H, -FT_H);                  // 6
+    r[15] = ft_mul_h(r[15], -FT_C8, FT_S8);                 // 9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) ft_bfly4(r[4 * k1], r[4 * k1 + 1], r[4 * k1 + 2], r[4 * k1 + 3]);   // r[k2 + 4 k1] = X[k1 + 4 k2]
+}
+template <class LoadF, class StoreF>
+__device__ __forceinline__ void ft16_run(double2 *buf, int n, int s, const double2 *__restrict__ tw4096, LoadF load, StoreF store)
+{
+    const int t = threadIdx.x;
+    double2 r[16];
+    bool first = true;
+    while (n >= 16) {
+        const int n1 = n >> 4;
+        const int sh = __ffs(s) - 1;
+        const int p = t >> sh, q = t & (s - 1);
+        const bool last = n1 == 1;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int idx = q + ((p + j * n1) << sh);
+            r[j] = first ? load(idx, j) : buf[ft16_pad(idx)];
+        }
+        ft_radix16(r);
+        if (!first && !last) FT_BARRIER();            // every lane has read the tile before anyone overwrites it
+        const int tws = 4096 / n;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            double2 v = r[(k >> 2) + 4 * (k & 3)];
+            if (k > 0 && p > 0) v = cmul_d(v, tw4096[p * k * tws]);
+            const int o = q + ((16 * p + k) << sh);
+            if (last) store(o, v, k); else buf[ft16_pad(o)] = v;
+        }
+        if (!last) FT_BARRIER();
+        n = n1; s <<= 4; first = false;
+    }
+    if (n > 1) {     // the last pass, radix n in {2, 4, 8}: the lane's elements are t + 256 m, butterflies over m
+#pragma unroll
+        for (int m = 0; m < 16; m++) r[m] = first ? load(t + 256 * m, m) : buf[ft16_pad(t + 256 * m)];
+        if (n == 2) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) ft_bfly2(r[u], r[u + 8]);
+        } else if (n == 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) ft_bfly4(r[u], r[u + 4], r[u + 8], r[u + 12]);
+        } else {    // 8 = 2 x 4: element j = m >> 1 of butterfly u = m & 1; j = j0 + 2 j1
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                ft_bfly4(r[u], r[u + 4], r[u + 8], r[u + 12]);              // j0 = 0: j = 0, 2, 4, 6 -> k1 at r[u + 4 k1]
+                ft_bfly4(r[u + 2], r[u + 6], r[u + 10], r[u + 14]);         // j0 = 1: j = 1, 3, 5, 7 -> k1 at r[u + 2 + 4 k1]
+                r[u + 6] = ft_mul_h(r[u + 6], FT_H, -FT_H);                 // W8^1
+                r[u + 10] = make_double2(r[u + 10].y, -r[u + 10].x);        // W8^2 = -i
+                r[u + 14] = ft_mul_h(r[u + 14], -FT_H, -FT_H);              // W8^3
+#pragma unroll
+                for (int k1 = 0; k1 < 4; k1++) ft_bfly2(r[u + 4 * k1], r[u + 2 + 4 * k1]);   // X[k1] at r[u + 4 k1], X[k1 + 4] at r[u + 2 + 4 k1]
+            }
+        }
+        // output k of butterfly u sits at element u' + (16 / n) k  (same slots as the inputs)
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            int src = m;
+            if (n == 8) { const int u = m & 1, k = m >> 1; src = u + 4 * (k & 3) + 2 * (k >> 2); }
+            store(t + 256 * m, r[src], m);
+        }
+    }
+}
+
+// Four-step FFT of the display spectrum, N = N1 x 4096, F frames per launch (blockIdx.y = frame):
+//   pass A (k_fft_cols)  N1-point FFTs down the columns, 4096/N1 columns per workgroup; periodic Hann window on load, computed
+//                        from the twiddle tables: w[i] = 0.5 + 0.5 cos(2 pi (i - N/2) / N) = 0.5 - 0.5 Re W_N^i (quisk.c:5091-5096;
+//                        no 8 B/sample window table is streamed); twiddle W_N^(n2 k1) on store; Y[f][k1][n2] to HBM
+//   pass B (k_fft_rows)  4096-point FFT of each row Y[f][k1][.]; the workgroup walks the F frames of its row and adds up |X| in
+//                        registers: the average is read-modified-written once per launch, not per frame (or just written, when
+//                        the launch starts a new average)
+// pass A: blockIdx.x = column tile; TW = 4096 / N1 columns per tile
+__global__ __launch_bounds__(FT16_THREADS) void k_fft_cols(FftArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double2 buf[FT16_LDS];
+    const int N1 = a.N1, TW = 4096 / N1, tsh = __ffs(TW) - 1;
     const int c0 = blockIdx.x * TW;
-    for (int e = threadIdx.x; e < 4096; e += FFT_BIG_THREADS) {
-        const int n1 = e / TW, col = e - n1 * TW;
-        const long long idx = (long long)n1 * 4096 + c0 + col;          // x[N2 n1 + n2]
-        const double2 v = a.x[idx];
-        const double w = a.window[idx];
-        buf[e] = make_double2(v.x * w, v.y * w);
-    }
-    lds_fft<4096, FFT_BIG_THREADS>(buf, N1, TW, a.tw4096);
-    for (int e = threadIdx.x; e < 4096; e += FFT_BIG_THREADS) {
-        const int k1 = e / TW, col = e - k1 * TW;
-        const int n2 = c0 + col;
+    const double2 *__restrict__ x = a.x + (long long)blockIdx.y * a.N;
+    double2 *__restrict__ Y = a.Y + (long long)blockIdx.y * a.N;
+    const double2 *__restrict__ tlo = a.tw_lo, *__restrict__ thi = a.tw_hi;
+    auto load = [&](int idx, int) {
+        const int n1 = idx >> tsh, col = idx & (TW - 1);
+        const int g = n1 * 4096 + c0 + col;                              // x[N2 n1 + n2]
+        const double2 v = x[g];
+        const double2 wh = thi[g >> 10], wl = tlo[g & 1023];
+        const double w = 0.5 - 0.5 * (wh.x * wl.x - wh.y * wl.y);
+        return make_double2(v.x * w, v.y * w);
+    };
+    auto store = [&](int o, double2 v, int) {
+        const int k1 = o >> tsh, n2 = c0 + (o & (TW - 1));
         const long long t = (long long)n2 * k1;                          // < N
-        const double2 w = cmul_d(a.tw_hi[t >> 10], a.tw_lo[t & 1023]);
-        a.Y[(long long)k1 * 4096 + n2] = cmul_d(buf[e], w);
-    }
+        const double2 w = cmul_d(thi[t >> 10], tlo[t & 1023]);
+        Y[(long long)k1 * 4096 + n2] = cmul_d(v, w);
+    };
+    ft16_run(buf, N1, TW, a.tw4096, load, store);
 }
 
 // pass B: blockIdx.x = k1
-__global__ __launch_bounds__(FFT_BIG_THREADS) void k_fft_rows(FftArgs a)
+__global__ __launch_bounds__(FT16_THREADS) void k_fft_rows(FftArgs a)
 {
-    __shared__ __attribute__((aligned(16))) double2 buf[4096];
+    __shared__ __attribute__((aligned(16))) double2 buf[FT16_LDS];
     const int k1 = blockIdx.x;
-    const double2 *row = a.Y + (long long)k1 * 4096;
-    for (int e = threadIdx.x; e < 4096; e += FFT_BIG_THREADS) buf[e] = row[e];
-    lds_fft<4096, FFT_BIG_THREADS>(buf, 4096, 1, a.tw4096);
-    for (int e = threadIdx.x; e < 4096; e += FFT_BIG_THREADS) fft_epilogue(a, k1, e, buf[e]);
+    double acc[16];
+    double2 nxt[16], cur[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) { acc[m] = 0.0; nxt[m] = a.Y[(long long)k1 * 4096 + threadIdx.x + 256 * m]; }
+    for (int f = 0; f < a.frames; f++) {
+        // the row of the next frame is on its way while this one is transformed (first pass of a 4096-point row: element
+        // threadIdx.x + 256 j is the lane's operand j)
+#pragma unroll
+        for (int m = 0; m < 16; m++) cur[m] = nxt[m];
+        if (f + 1 < a.frames) {
+            const double2 *__restrict__ nrow = a.Y + (long long)(f + 1) * a.N + (long long)k1 * 4096;
+#pragma unroll
+            for (int m = 0; m < 16; m++) nxt[m] = nrow[threadIdx.x + 256 * m];
+        }
+        double *__restrict__ band = a.band + (long long)f * a.band_stride;
+        auto load = [&](int, int slot) { return cur[slot]; };
+        auto store = [&](int e, double2 X, int slot) {
+            acc[slot] += hypot(X.x, X.y);                                 // cabs, quisk.c:4707-4709; frames in order
+            const int k = k1 + a.N1 * e;
+            const int sk = k < a.N / 2 ? k : k - a.N;                     // signed bin number
+            const int j = sk - a.band_start;
+            if (j >= 0 && j < a.band_count) band[j] = X.x * X.x + X.y * X.y;   // c * conj(c), quisk.c:4673
+        };
+        if (f) FT_BARRIER();
+        ft16_run(buf, 4096, 1, a.tw4096, load, store);
+    }
+    // the lane's element of slot m is e = threadIdx.x + 256 m (a 4096-point row always ends on a radix-16 pass: o = q + 256 k)
+    double *__restrict__ avg = a.avg + (long long)k1 * 4096;
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        const int e = threadIdx.x + 256 * m;
+        avg[e] = a.accumulate ? avg[e] + acc[m] : acc[m];
+    }
 }
 
-// S-meter accumulation of one frame, in the reference's order (quisk.c:4668-4679): whole bins, then the
-// fractional bin.  One thread.
-__global__ void k_meter_accum(const double *band, int n_whole, double frac, double *meter)
+// S-meter accumulation of `frames` frames, in the reference's order (quisk.c:4668-4679): whole bins, then the
+// fractional bin, frame after frame.  One thread.
+__global__ void k_meter_accum(const double *band, int n_whole, double frac, double *meter, int frames, int band_stride)
 {
 #pragma clang fp contract(off)
     if (threadIdx.x || blockIdx.x) return;
     double m = *meter;
-    for (int j = 0; j < n_whole; j++) m = m + band[j];
-    m = m + band[n_whole] * frac;
+    for (int f = 0; f < frames; f++, band += band_stride) {
+        for (int j = 0; j < n_whole; j++) m = m + band[j];
+        m = m + band[n_whole] * frac;
+    }
     *meter = m;
 }
 

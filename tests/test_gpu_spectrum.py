@@ -82,3 +82,28 @@ def test_four_step_sizes(N, W):
     eng.process(x2[:N // 2]); eng.process(x2[N // 2:]); og.add_frames(x2)
     assert _cmp(eng, og, zoom=0.5, deltaf=1.0e6) == 1
     eng.close(); og.close()
+
+
+@pytest.mark.parametrize("N,W", [(8192, 1024), (131072, 2048), (1 << 20, 4096)])
+def test_four_step_batched_frames(N, W):
+    """Blocks that hold several whole frames: the four-step passes take up to eight frames per launch, add their magnitudes
+    up in registers and write the average once (a launch that starts a new average overwrites it, a later one adds); the
+    S-meter sums the frames' pass-band bins frame after frame in the reference's order (one USB receiver supplies the band)."""
+    fs = 1536000 if N < (1 << 20) else 61440000
+    eng = Engine(fs, n_receivers=1, max_block=5 * N, fft_size=N, data_width=W)
+    og = B.OracleGraph(N, W, fs)
+    fi, fq, bw, off = rx_filter(fs, 3)
+    tune = int(0.11 * fs)
+    eng.set_mode(0, 3); eng.set_tune(0, tune); eng.set_filters(0, fi, fq, bw, off)
+    og.set_passband(tune, off, bw)
+    x = make_iq(13 * N, fs, [tune, -int(0.3 * fs)], [3, 3], 1003)
+    eng.process(x[:5 * N])                  # five frames in one launch pair: a new average
+    eng.process(x[5 * N:8 * N])             # three more: added to it
+    og.add_frames(x[:8 * N])
+    assert eng.graph_pending() == 8
+    assert _cmp(eng, og) == 8
+    eng.process(x[8 * N:8 * N + 1000])      # a ragged start, then frames from the staging buffer and straight from the block
+    eng.process(x[8 * N + 1000:13 * N])
+    og.add_frames(x[8 * N:13 * N])
+    assert _cmp(eng, og, zoom=0.5, deltaf=fs / 16.0) == 5
+    eng.close(); og.close()
