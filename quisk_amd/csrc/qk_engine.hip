@@ -34,6 +34,7 @@ namespace {
 
 constexpr int DEFAULT_TAP_CAP = 1024;
 constexpr int FFT_BATCH = 8;          // display-spectrum frames per four-step launch
+constexpr int FFT_GROUPS = 2;         // frame groups of the four-step row pass, each with its own partial average
 constexpr int EV_POOL = 2048;
 
 enum StageKind { ST_FIR, ST_INTERP, ST_HBINT, ST_RESAMP, ST_RXF, ST_FMDISC, ST_IIR, ST_FRAC };
@@ -161,6 +162,9 @@ struct qk_engine {
     std::vector<int> out_count;
     // display spectrum (get_graph)
     int fftN = 0, fftN1 = 1, fftW = 0, fft_fill = 0, fft_count = 0;
+    int fft_parts = 0;                     // partial averages of the four-step row pass that hold data (0 after a release)
+    double *h_graph = nullptr;             // pinned staging of a released row + the S-meter sum
+    double k0_zoom = 0, k0_deltaf = 0; bool k0_valid = false;     // what d_k0 was made for
     double2 *d_fft_stage = nullptr, *d_fft_Y = nullptr, *d_tw4096 = nullptr, *d_tw_lo = nullptr, *d_tw_hi = nullptr;
     double *d_window = nullptr, *d_fft_avg = nullptr, *d_band = nullptr, *d_meter = nullptr, *d_graph = nullptr, *d_pix = nullptr;
     int *d_k0 = nullptr;
@@ -994,13 +998,15 @@ static int init_spectrum(qk_engine *e)
     HIPCHECK(hipMalloc(&e->d_fft_stage, sizeof(double2) * N));
     if (e->blue) HIPCHECK(hipMalloc(&e->d_fft_Y, sizeof(double2) * N));
     else if (e->fftN1 > 1) HIPCHECK(hipMalloc(&e->d_fft_Y, sizeof(double2) * N * FFT_BATCH));      // Y of up to FFT_BATCH frames per launch
-    HIPCHECK(hipMalloc(&e->d_fft_avg, sizeof(double) * N));
-    HIPCHECK(hipMemset(e->d_fft_avg, 0, sizeof(double) * N));
+    const int parts = e->fftN1 > 1 ? FFT_GROUPS : 1;
+    HIPCHECK(hipMalloc(&e->d_fft_avg, sizeof(double) * N * parts));
+    HIPCHECK(hipMemset(e->d_fft_avg, 0, sizeof(double) * N * parts));
+    HIPCHECK(hipHostMalloc(&e->h_graph, sizeof(double) * (W + 1), hipHostMallocDefault));
     e->band_cap = N / 2 + 2;
     HIPCHECK(hipMalloc(&e->d_band, sizeof(double) * e->band_cap * FFT_BATCH));
     HIPCHECK(hipMalloc(&e->d_meter, sizeof(double)));
     HIPCHECK(hipMemset(e->d_meter, 0, sizeof(double)));
-    HIPCHECK(hipMalloc(&e->d_graph, sizeof(double) * W));
+    HIPCHECK(hipMalloc(&e->d_graph, sizeof(double) * (W + 1)));      // [W] = the S-meter sum at release
     HIPCHECK(hipMalloc(&e->d_pix, sizeof(double) * W));
     HIPCHECK(hipMalloc(&e->d_k0, sizeof(int) * W));
     return QK_OK;
@@ -1014,7 +1020,7 @@ static void fft_frames(qk_engine *e, const double2 *frame, int frames)
     FftArgs a{};
     a.x = frame; a.window = e->d_window; a.tw4096 = e->d_tw4096; a.tw_lo = e->d_tw_lo; a.tw_hi = e->d_tw_hi;
     a.Y = e->d_fft_Y; a.avg = e->d_fft_avg; a.band = e->d_band; a.N = N; a.N1 = e->fftN1;
-    a.frames = frames; a.band_stride = e->band_cap; a.accumulate = e->fft_count > 0;
+    a.frames = frames; a.band_stride = e->band_cap; a.acc_parts = e->fft_parts;
     // S-meter pass band of receiver 0 (quisk.c:4659-4667)
     const int fs = e->cfg.sample_rate;
     const int bw = e->nrx > 0 ? e->bandwidth[0] : 0;
@@ -1030,8 +1036,16 @@ static void fft_frames(qk_engine *e, const double2 *frame, int frames)
         blue_run(e, e->blue, e->fe_stream, frame, nullptr, e->d_fft_Y);
         hipLaunchKernelGGL(k_graph_accum, dim3((N + 255) / 256), dim3(256), 0, e->fe_stream, e->d_fft_Y, a);
     } else if (e->fftN1 > 1) {
-        hipLaunchKernelGGL(k_fft_cols, dim3(e->fftN1, frames), dim3(FT16_THREADS), 0, e->fe_stream, a);
-        hipLaunchKernelGGL(k_fft_rows, dim3(e->fftN1), dim3(FT16_THREADS), 0, e->fe_stream, a);
+        const dim3 gc(e->fftN1, frames);      // N1 column tiles of 4096 / N1 columns each
+        switch (e->fftN1) {
+#define QK_COLS(n1) case n1: hipLaunchKernelGGL(k_fft_cols<n1>, gc, dim3(FT16_THREADS), 0, e->fe_stream, a); break
+        QK_COLS(2); QK_COLS(4); QK_COLS(8); QK_COLS(16); QK_COLS(32); QK_COLS(64); QK_COLS(128); QK_COLS(256);
+        QK_COLS(512); QK_COLS(1024); QK_COLS(2048); QK_COLS(4096);
+#undef QK_COLS
+        }
+        const int groups = std::min(frames, FFT_GROUPS);
+        hipLaunchKernelGGL(k_fft_rows, dim3(e->fftN1, groups), dim3(FT16_THREADS), 0, e->fe_stream, a);
+        e->fft_parts = std::max(e->fft_parts, groups);
     } else {
         switch (N) {
         case 64: hipLaunchKernelGGL(k_fft_small<64>, dim3(1), dim3(FFT_THREADS), 0, e->fe_stream, a); break;
@@ -1079,24 +1093,32 @@ static int release_graph(qk_engine *e, double zoom, double deltaf, double *out, 
     if (count <= 0) return 0;
     int n = (int)(zoom * (double)N / W + 0.5);                      // quisk.c:4715-4717
     if (n < 1) n = 1;
-    std::vector<int> k0(W);
+    // first bin of every pixel (quisk.c:4720-4721); uploaded only when zoom or deltaf changed
+    static thread_local std::vector<int> k0;
+    k0.resize(W);
     bool alias = false;
     for (int i = 0; i < W; i++) {
-        k0[i] = (int)(N * (deltaf / e->cfg.sample_rate + zoom * ((double)i / W - 0.5) + 0.5) + 0.1);   // quisk.c:4720-4721
+        k0[i] = (int)(N * (deltaf / e->cfg.sample_rate + zoom * ((double)i / W - 0.5) + 0.5) + 0.1);
         if (i >= 1 && k0[i] < i && k0[i] + n - 1 >= 0) alias = true;   // would read a pixel already written in place
     }
-    HIPCHECK(hipMemcpyAsync(e->d_k0, k0.data(), sizeof(int) * W, hipMemcpyHostToDevice, e->fe_stream));
+    if (!e->k0_valid || e->k0_zoom != zoom || e->k0_deltaf != deltaf) {
+        HIPCHECK(hipStreamSynchronize(e->fe_stream));              // (a release still reading the old table)
+        HIPCHECK(hipMemcpy(e->d_k0, k0.data(), sizeof(int) * W, hipMemcpyHostToDevice));
+        e->k0_valid = true; e->k0_zoom = zoom; e->k0_deltaf = deltaf;
+    }
     ReleaseArgs ra{e->d_fft_avg, e->d_graph, e->d_k0, N, e->fftN1, W, n,
-                   20.0 * (log10((double)count) + log10((double)N) + 31.0 * log10(2.0))};          // quisk.c:4741-4742
+                   20.0 * (log10((double)count) + log10((double)N) + 31.0 * log10(2.0)),          // quisk.c:4741-4742
+                   e->fftN1 > 1 ? std::max(1, e->fft_parts) : 1, e->d_meter};
     if (alias) hipLaunchKernelGGL(k_graph_release_inplace, dim3(1), dim3(256), 0, e->fe_stream, ra, e->d_pix);
-    else hipLaunchKernelGGL(k_graph_release, dim3((W + 3) / 4), dim3(256), 0, e->fe_stream, ra);
-    double meter = 0;
-    HIPCHECK(hipMemcpyAsync(out, e->d_graph, sizeof(double) * W, hipMemcpyDeviceToHost, e->fe_stream));
-    HIPCHECK(hipMemcpyAsync(&meter, e->d_meter, sizeof(double), hipMemcpyDeviceToHost, e->fe_stream));
+    else hipLaunchKernelGGL(k_graph_release, dim3((W + REL_PIX - 1) / REL_PIX), dim3(64 * REL_PIX), 0, e->fe_stream, ra);
+    // one copy brings the row and the S-meter sum (the kernel left it behind the row and cleared the accumulator)
+    HIPCHECK(hipMemcpyAsync(e->h_graph, e->d_graph, sizeof(double) * (W + 1), hipMemcpyDeviceToHost, e->fe_stream));
     if (e->fftN1 <= 1)      // (the four-step pass B overwrites the average when it starts a new one: no 8 N bytes of zeros)
         HIPCHECK(hipMemsetAsync(e->d_fft_avg, 0, sizeof(double) * N, e->fe_stream));
-    HIPCHECK(hipMemsetAsync(e->d_meter, 0, sizeof(double), e->fe_stream));
     HIPCHECK(hipStreamSynchronize(e->fe_stream));
+    memcpy(out, e->h_graph, sizeof(double) * W);
+    const double meter = e->h_graph[W];
+    e->fft_parts = 0;
     const double scale = 1.0 / 2147483647.0 / N;                    // quisk.c:4728-4737
     double sm = meter * scale * scale / count;
     sm = sm > 0 ? 10.0 * log10(sm) : -160.0;
@@ -1586,6 +1608,7 @@ void qk_destroy(qk_engine *e)
                     e->d_fft_stage, e->d_fft_Y, e->d_tw4096, e->d_tw_lo, e->d_tw_hi, e->d_window, e->d_fft_avg, e->d_band,
                     e->d_meter, e->d_graph, e->d_pix, e->d_k0};
     for (void *p : ptrs) if (p) hipFree(p);
+    if (e->h_graph) hipHostFree(e->h_graph);
     for (auto &ev : e->ev_pool) if (ev) hipEventDestroy(ev);
     if (e->agc_stream) { hipStreamSynchronize(e->agc_stream); hipStreamDestroy(e->agc_stream); }
     if (e->apply_stream) { hipStreamSynchronize(e->apply_stream); hipStreamDestroy(e->apply_stream); }

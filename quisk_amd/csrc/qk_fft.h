@@ -102,12 +102,12 @@ struct FftArgs {
     const double2 *tw4096;     // exp(-2 pi i j / 4096)
     const double2 *tw_lo, *tw_hi;   // four-step twiddles: W_N^j (j < 1024) and W_N^(1024 j)
     double2 *Y;                // four-step intermediate [N1][4096]
-    double *avg;               // magnitude sum, layout [k1][k2] with k = k1 + N1 k2  (N1 = 1: natural order)
+    double *avg;               // magnitude sum, layout [k1][k2] with k = k1 + N1 k2  (N1 = 1: natural order); four-step: [group][k1][k2]
     double *band;              // |X|^2 of the S-meter pass-band bins of this frame (quisk.c:4659-4680)
     int N, N1;
     int band_start, band_count;   // first bin (signed, relative to DC) and number of bins kept (whole + fractional)
     int frames, band_stride;      // four-step passes: frames per launch (consecutive in x and Y), doubles between the frames' band arrays
-    int accumulate;               // four-step pass B: 0 = this launch starts a new average (write), 1 = add to it
+    int acc_parts;                // four-step pass B: group g adds to its partial average if g < acc_parts, else writes it (starts it)
 };
 
 // epilogue shared by the single-workgroup FFT and pass B: element e of the row is X[k1 + N1 e]
@@ -185,136 +185,231 @@ __device__ __forceinline__ void ft_radix16(double2 (&r)[16])
 #pragma unroll
     for (int k1 = 0; k1 < 4; k1++) ft_bfly4(r[4 * k1], r[4 * k1 + 1], r[4 * k1 + 2], r[4 * k1 + 3]);   // r[k2 + 4 k1] = X[k1 + 4 k2]
 }
-template <class LoadF, class StoreF>
-__device__ __forceinline__ void ft16_run(double2 *buf, int n, int s, const double2 *__restrict__ tw4096, LoadF load, StoreF store)
+template <int V> struct FtLog2 { static constexpr int value = 1 + FtLog2<V / 2>::value; };
+template <> struct FtLog2<1> { static constexpr int value = 0; };
+// W16^j = exp(-2 pi i j / 16) as compile-time constants (j is a constant after unrolling)
+__device__ __forceinline__ constexpr double ft_cos16(int j)
 {
+    constexpr double c[16] = {1.0, FT_C8, FT_H, FT_S8, 0.0, -FT_S8, -FT_H, -FT_C8, -1.0, -FT_C8, -FT_H, -FT_S8, 0.0, FT_S8, FT_H, FT_C8};
+    return c[j & 15];
+}
+__device__ __forceinline__ constexpr double ft_sin16(int j) { return ft_cos16(j + 12); }        // sin(2 pi j / 16)
+// register slot of X[k] after ft_radix16
+__device__ __forceinline__ constexpr int ft_slot16(int k) { return (k >> 2) + 4 * (k & 3); }
+
+// One radix-16 Stockham pass with compile-time geometry: the tile holds S = 4096 / NN interleaved sequences of length NN.
+// The lane's operands are the tile elements t + 256 j (always: NN / 16 * S = 256); X[k] goes to tile index
+// q + S (16 p + k).  The fifteen twiddles W_NN^(p k) come from four table entries (k = 1, 2, 4, 8, loaded before the
+// butterfly) and eleven products.  FROM_REGS: operands already in r; TO_REGS: X[k] stays in r[ft_slot16(k)].
+template <int NN, bool FROM_REGS, bool TO_REGS>
+__device__ __forceinline__ void ft_pass16(double2 (&r)[16], double2 *buf, const double2 *__restrict__ tw4096)
+{
+    constexpr int S = 4096 / NN, SH = FtLog2<S>::value, SUB = NN / 16;
     const int t = threadIdx.x;
-    double2 r[16];
-    bool first = true;
-    while (n >= 16) {
-        const int n1 = n >> 4;
-        const int sh = __ffs(s) - 1;
-        const int p = t >> sh, q = t & (s - 1);
-        const bool last = n1 == 1;
+    const int p = t >> SH, q = t & (S - 1);
+    double2 w1, w2, w4, w8;
+    if constexpr (SUB > 1) {
+        w1 = tw4096[p * S]; w2 = tw4096[2 * p * S]; w4 = tw4096[4 * p * S]; w8 = tw4096[8 * p * S];
+    }
+    if constexpr (!FROM_REGS) {
+        const int base = t + (t >> 4);
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int idx = q + ((p + j * n1) << sh);
-            r[j] = first ? load(idx, j) : buf[ft16_pad(idx)];
-        }
-        ft_radix16(r);
-        if (!first && !last) FT_BARRIER();            // every lane has read the tile before anyone overwrites it
-        const int tws = 4096 / n;
+        for (int j = 0; j < 16; j++) r[j] = buf[base + 272 * j];
+    }
+    ft_radix16(r);
+    if constexpr (SUB > 1) {
+        const double2 w3 = cmul_d(w1, w2), w5 = cmul_d(w1, w4), w6 = cmul_d(w2, w4), w7 = cmul_d(w3, w4);
+        r[ft_slot16(1)] = cmul_d(r[ft_slot16(1)], w1);   r[ft_slot16(2)] = cmul_d(r[ft_slot16(2)], w2);
+        r[ft_slot16(3)] = cmul_d(r[ft_slot16(3)], w3);   r[ft_slot16(4)] = cmul_d(r[ft_slot16(4)], w4);
+        r[ft_slot16(5)] = cmul_d(r[ft_slot16(5)], w5);   r[ft_slot16(6)] = cmul_d(r[ft_slot16(6)], w6);
+        r[ft_slot16(7)] = cmul_d(r[ft_slot16(7)], w7);   r[ft_slot16(8)] = cmul_d(r[ft_slot16(8)], w8);
+        r[ft_slot16(9)] = cmul_d(r[ft_slot16(9)], cmul_d(w1, w8));    r[ft_slot16(10)] = cmul_d(r[ft_slot16(10)], cmul_d(w2, w8));
+        r[ft_slot16(11)] = cmul_d(r[ft_slot16(11)], cmul_d(w3, w8));  r[ft_slot16(12)] = cmul_d(r[ft_slot16(12)], cmul_d(w4, w8));
+        r[ft_slot16(13)] = cmul_d(r[ft_slot16(13)], cmul_d(w5, w8));  r[ft_slot16(14)] = cmul_d(r[ft_slot16(14)], cmul_d(w6, w8));
+        r[ft_slot16(15)] = cmul_d(r[ft_slot16(15)], cmul_d(w7, w8));
+    }
+    if constexpr (!TO_REGS) {
+        if constexpr (!FROM_REGS) FT_BARRIER();       // every lane has read the tile before anyone overwrites it
+        const int o0 = q + ((16 * p) << SH);
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            double2 v = r[(k >> 2) + 4 * (k & 3)];
-            if (k > 0 && p > 0) v = cmul_d(v, tw4096[p * k * tws]);
-            const int o = q + ((16 * p + k) << sh);
-            if (last) store(o, v, k); else buf[ft16_pad(o)] = v;
+            const int o = o0 + (k << SH);
+            buf[o + (o >> 4)] = r[ft_slot16(k)];
         }
-        if (!last) FT_BARRIER();
-        n = n1; s <<= 4; first = false;
+        FT_BARRIER();
     }
-    if (n > 1) {     // the last pass, radix n in {2, 4, 8}: the lane's elements are t + 256 m, butterflies over m
+}
+// The last pass of a tile whose sequences are shorter than 16: radix NN in {2, 4, 8}, no twiddles.  The lane's elements are
+// t + 256 m; the result for tile index t + 256 m is left in r[ft_final_slot<NN>(m)].
+template <int NN> __device__ __forceinline__ constexpr int ft_final_slot(int m)
+{
+    if (NN == 8) { const int u = m & 1, k = m >> 1; return u + 4 * (k & 3) + 2 * (k >> 2); }
+    return m;
+}
+template <int NN, bool FROM_REGS>
+__device__ __forceinline__ void ft_final(double2 (&r)[16], double2 *buf)
+{
+    if constexpr (!FROM_REGS) {
+        const int t = threadIdx.x, base = t + (t >> 4);
 #pragma unroll
-        for (int m = 0; m < 16; m++) r[m] = first ? load(t + 256 * m, m) : buf[ft16_pad(t + 256 * m)];
-        if (n == 2) {
+        for (int m = 0; m < 16; m++) r[m] = buf[base + 272 * m];
+    }
+    if constexpr (NN == 2) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) ft_bfly2(r[u], r[u + 8]);
-        } else if (n == 4) {
+        for (int u = 0; u < 8; u++) ft_bfly2(r[u], r[u + 8]);
+    } else if constexpr (NN == 4) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) ft_bfly4(r[u], r[u + 4], r[u + 8], r[u + 12]);
-        } else {    // 8 = 2 x 4: element j = m >> 1 of butterfly u = m & 1; j = j0 + 2 j1
+        for (int u = 0; u < 4; u++) ft_bfly4(r[u], r[u + 4], r[u + 8], r[u + 12]);
+    } else {    // 8 = 2 x 4: element j = m >> 1 of butterfly u = m & 1; j = j0 + 2 j1
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                ft_bfly4(r[u], r[u + 4], r[u + 8], r[u + 12]);              // j0 = 0: j = 0, 2, 4, 6 -> k1 at r[u + 4 k1]
-                ft_bfly4(r[u + 2], r[u + 6], r[u + 10], r[u + 14]);         // j0 = 1: j = 1, 3, 5, 7 -> k1 at r[u + 2 + 4 k1]
-                r[u + 6] = ft_mul_h(r[u + 6], FT_H, -FT_H);                 // W8^1
-                r[u + 10] = make_double2(r[u + 10].y, -r[u + 10].x);        // W8^2 = -i
-                r[u + 14] = ft_mul_h(r[u + 14], -FT_H, -FT_H);              // W8^3
+        for (int u = 0; u < 2; u++) {
+            ft_bfly4(r[u], r[u + 4], r[u + 8], r[u + 12]);              // j0 = 0: j = 0, 2, 4, 6 -> k1 at r[u + 4 k1]
+            ft_bfly4(r[u + 2], r[u + 6], r[u + 10], r[u + 14]);         // j0 = 1: j = 1, 3, 5, 7 -> k1 at r[u + 2 + 4 k1]
+            r[u + 6] = ft_mul_h(r[u + 6], FT_H, -FT_H);                 // W8^1
+            r[u + 10] = make_double2(r[u + 10].y, -r[u + 10].x);        // W8^2 = -i
+            r[u + 14] = ft_mul_h(r[u + 14], -FT_H, -FT_H);              // W8^3
 #pragma unroll
-                for (int k1 = 0; k1 < 4; k1++) ft_bfly2(r[u + 4 * k1], r[u + 2 + 4 * k1]);   // X[k1] at r[u + 4 k1], X[k1 + 4] at r[u + 2 + 4 k1]
-            }
-        }
-        // output k of butterfly u sits at element u' + (16 / n) k  (same slots as the inputs)
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-            int src = m;
-            if (n == 8) { const int u = m & 1, k = m >> 1; src = u + 4 * (k & 3) + 2 * (k >> 2); }
-            store(t + 256 * m, r[src], m);
+            for (int k1 = 0; k1 < 4; k1++) ft_bfly2(r[u + 4 * k1], r[u + 2 + 4 * k1]);   // X[k1] at r[u + 4 k1], X[k1 + 4] at r[u + 2 + 4 k1]
         }
     }
 }
+// The whole tile: radix-16 passes while the sequences have at least 16 elements, then the short last pass.  In: r[j] = tile
+// element t + 256 j.  Out: the transform's value at tile index t + 256 m (= sequence q, frequency pos, index q + S pos) is
+// r[ft_out_slot<NN>(m)].  A 4096-point row makes two trips through LDS, a 256-point column tile one, a 16-point one none.
+// The caller puts a barrier between two tiles that use the same buffer.
+template <int NN, bool FIRST = true>
+__device__ __forceinline__ void ft_run(double2 (&r)[16], double2 *buf, const double2 *__restrict__ tw4096)
+{
+    if constexpr (NN >= 16) {
+        ft_pass16<NN, FIRST, NN == 16>(r, buf, tw4096);
+        if constexpr (NN > 16) ft_run<NN / 16, false>(r, buf, tw4096);
+    } else if constexpr (NN > 1) {
+        ft_final<NN, FIRST>(r, buf);
+    }
+}
+template <int NN> __device__ __forceinline__ constexpr int ft_out_slot(int m)
+{
+    int n = NN;
+    while (n > 16) n /= 16;
+    return n == 16 ? ft_slot16(m) : n == 8 ? ft_final_slot<8>(m) : m;
+}
 
-// Four-step FFT of the display spectrum, N = N1 x 4096, F frames per launch (blockIdx.y = frame):
-//   pass A (k_fft_cols)  N1-point FFTs down the columns, 4096/N1 columns per workgroup; periodic Hann window on load, computed
-//                        from the twiddle tables: w[i] = 0.5 + 0.5 cos(2 pi (i - N/2) / N) = 0.5 - 0.5 Re W_N^i (quisk.c:5091-5096;
-//                        no 8 B/sample window table is streamed); twiddle W_N^(n2 k1) on store; Y[f][k1][n2] to HBM
-//   pass B (k_fft_rows)  4096-point FFT of each row Y[f][k1][.]; the workgroup walks the F frames of its row and adds up |X| in
-//                        registers: the average is read-modified-written once per launch, not per frame (or just written, when
-//                        the launch starts a new average)
-// pass A: blockIdx.x = column tile; TW = 4096 / N1 columns per tile
-__global__ __launch_bounds__(FT16_THREADS) void k_fft_cols(FftArgs a)
+// Four-step FFT of the display spectrum, N = N1 x 4096, F frames per launch:
+//   pass A (k_fft_cols<N1>, blockIdx.y = frame)  N1-point FFTs down the columns, 4096/N1 columns per workgroup; periodic Hann
+//        window on load, computed from the twiddle tables: w[i] = 0.5 + 0.5 cos(2 pi (i - N/2) / N) = 0.5 - 0.5 Re W_N^i
+//        (quisk.c:5091-5096; no 8 B/sample window table is streamed).  The lane's sixteen samples are 4096 N1/16 apart, so
+//        W_N^i = (one table product per lane) x W16^j with compile-time W16.  Twiddle W_N^(n2 k1) on store; Y[f][k1][n2] to HBM.
+//   pass B (k_fft_rows, blockIdx.y = group)  4096-point FFT of each row Y[f][k1][.]; the workgroup walks the frames f = g,
+//        g + G, ... of its row (the next one's loads in flight while this one is transformed) and adds up |X| in registers:
+//        the average is read-modified-written once per launch, not per frame.  Group g keeps its own partial average
+//        avg[g][k1][k2] (summed by the release kernel), so two workgroups per CU work on different frames of a row.
+template <int N1>
+__global__ __launch_bounds__(FT16_THREADS, 2) void k_fft_cols(FftArgs a)
 {
     __shared__ __attribute__((aligned(16))) double2 buf[FT16_LDS];
-    const int N1 = a.N1, TW = 4096 / N1, tsh = __ffs(TW) - 1;
-    const int c0 = blockIdx.x * TW;
+    constexpr int TW = 4096 / N1, TSH = FtLog2<TW>::value;
+    const int t = threadIdx.x, c0 = blockIdx.x * TW;
     const double2 *__restrict__ x = a.x + (long long)blockIdx.y * a.N;
     double2 *__restrict__ Y = a.Y + (long long)blockIdx.y * a.N;
     const double2 *__restrict__ tlo = a.tw_lo, *__restrict__ thi = a.tw_hi;
-    auto load = [&](int idx, int) {
-        const int n1 = idx >> tsh, col = idx & (TW - 1);
-        const int g = n1 * 4096 + c0 + col;                              // x[N2 n1 + n2]
-        const double2 v = x[g];
-        const double2 wh = thi[g >> 10], wl = tlo[g & 1023];
-        const double w = 0.5 - 0.5 * (wh.x * wl.x - wh.y * wl.y);
-        return make_double2(v.x * w, v.y * w);
-    };
-    auto store = [&](int o, double2 v, int) {
-        const int k1 = o >> tsh, n2 = c0 + (o & (TW - 1));
-        const long long t = (long long)n2 * k1;                          // < N
-        const double2 w = cmul_d(thi[t >> 10], tlo[t & 1023]);
-        Y[(long long)k1 * 4096 + n2] = cmul_d(v, w);
-    };
-    ft16_run(buf, N1, TW, a.tw4096, load, store);
-}
-
-// pass B: blockIdx.x = k1
-__global__ __launch_bounds__(FT16_THREADS) void k_fft_rows(FftArgs a)
-{
-    __shared__ __attribute__((aligned(16))) double2 buf[FT16_LDS];
-    const int k1 = blockIdx.x;
-    double acc[16];
-    double2 nxt[16], cur[16];
+    double2 r[16];
+    if constexpr (N1 >= 16) {
+        const int gb = (t >> TSH) * 4096 + c0 + (t & (TW - 1));          // x[4096 n1 + n2], n1 = (t >> TSH) + (N1 / 16) j
+        const double2 wb = cmul_d(thi[gb >> 10], tlo[gb & 1023]);        // W_N^gb
 #pragma unroll
-    for (int m = 0; m < 16; m++) { acc[m] = 0.0; nxt[m] = a.Y[(long long)k1 * 4096 + threadIdx.x + 256 * m]; }
-    for (int f = 0; f < a.frames; f++) {
-        // the row of the next frame is on its way while this one is transformed (first pass of a 4096-point row: element
-        // threadIdx.x + 256 j is the lane's operand j)
+        for (int j = 0; j < 16; j++) r[j] = x[gb + j * (N1 / 16) * 4096];
 #pragma unroll
-        for (int m = 0; m < 16; m++) cur[m] = nxt[m];
-        if (f + 1 < a.frames) {
-            const double2 *__restrict__ nrow = a.Y + (long long)(f + 1) * a.N + (long long)k1 * 4096;
-#pragma unroll
-            for (int m = 0; m < 16; m++) nxt[m] = nrow[threadIdx.x + 256 * m];
+        for (int j = 0; j < 16; j++) {
+            const double w = 0.5 - 0.5 * (wb.x * ft_cos16(j) + wb.y * ft_sin16(j));       // Re(wb W16^j)
+            r[j] = make_double2(r[j].x * w, r[j].y * w);
         }
-        double *__restrict__ band = a.band + (long long)f * a.band_stride;
-        auto load = [&](int, int slot) { return cur[slot]; };
-        auto store = [&](int e, double2 X, int slot) {
-            acc[slot] += hypot(X.x, X.y);                                 // cabs, quisk.c:4707-4709; frames in order
-            const int k = k1 + a.N1 * e;
-            const int sk = k < a.N / 2 ? k : k - a.N;                     // signed bin number
-            const int j = sk - a.band_start;
-            if (j >= 0 && j < a.band_count) band[j] = X.x * X.x + X.y * X.y;   // c * conj(c), quisk.c:4673
-        };
-        if (f) FT_BARRIER();
-        ft16_run(buf, 4096, 1, a.tw4096, load, store);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int idx = t + 256 * m;
+            const int g = (idx >> TSH) * 4096 + c0 + (idx & (TW - 1));
+            const double2 v = x[g];
+            const double2 wh = thi[g >> 10], wl = tlo[g & 1023];
+            const double w = 0.5 - 0.5 * (wh.x * wl.x - wh.y * wl.y);
+            r[m] = make_double2(v.x * w, v.y * w);
+        }
     }
-    // the lane's element of slot m is e = threadIdx.x + 256 m (a 4096-point row always ends on a radix-16 pass: o = q + 256 k)
-    double *__restrict__ avg = a.avg + (long long)k1 * 4096;
+    ft_run<N1>(r, buf, a.tw4096);
 #pragma unroll
     for (int m = 0; m < 16; m++) {
-        const int e = threadIdx.x + 256 * m;
-        avg[e] = a.accumulate ? avg[e] + acc[m] : acc[m];
+        const int o = t + 256 * m;
+        const int k1 = o >> TSH, n2 = c0 + (o & (TW - 1));
+        const int tt = n2 * k1;                                          // < N <= 2^24
+        const double2 w = cmul_d(thi[tt >> 10], tlo[tt & 1023]);
+        Y[k1 * 4096 + n2] = cmul_d(r[ft_out_slot<N1>(m)], w);
+    }
+}
+
+// |X| = sqrt(s), s = re^2 + im^2 >= 0 far from the ends of the exponent range (samples are below 2^31, N <= 2^24): the
+// reciprocal square root seed and two coupled Newton steps, without the scaling a general sqrt needs; s = 0 gives 0.
+__device__ __forceinline__ double ft_sqrt_pos(double s)
+{
+    const double y = __builtin_amdgcn_rsq(fmax(s, 1e-280));
+    double g = s * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    const double d = fma(-g, g, s);
+    return fma(d, h, g);
+}
+// pass B: blockIdx.x = k1, blockIdx.y = frame group
+__global__ __launch_bounds__(FT16_THREADS, 2) void k_fft_rows(FftArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double2 buf[FT16_LDS];
+    const int t = threadIdx.x, k1 = blockIdx.x, g = blockIdx.y, G = gridDim.y;
+    const double2 *__restrict__ Yrow = a.Y + (long long)k1 * 4096 + t;
+    double acc[16];
+    double2 nxt[16], r[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) acc[m] = 0.0;
+    if (g < a.frames) {
+        const double2 *__restrict__ row = Yrow + (long long)g * a.N;
+#pragma unroll
+        for (int m = 0; m < 16; m++) nxt[m] = row[256 * m];
+    }
+    for (int f = g; f < a.frames; f += G) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) r[m] = nxt[m];
+        if (f + G < a.frames) {
+            const double2 *__restrict__ row = Yrow + (long long)(f + G) * a.N;
+#pragma unroll
+            for (int m = 0; m < 16; m++) nxt[m] = row[256 * m];
+        }
+        if (f != g) FT_BARRIER();
+        ft_run<4096>(r, buf, a.tw4096);
+        // X[k1 + N1 e], e = t + 256 k, is r[ft_slot16(k)]
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const double2 X = r[ft_slot16(k)];
+            acc[k] += ft_sqrt_pos(fma(X.x, X.x, X.y * X.y));                       // cabs, quisk.c:4707-4709; the group's frames in order
+        }
+        if (a.band_count > 0) {
+            double *__restrict__ band = a.band + (long long)f * a.band_stride;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const double2 X = r[ft_slot16(k)];
+                const int kk = k1 + a.N1 * (t + 256 * k);
+                const int sk = kk < a.N / 2 ? kk : kk - a.N;             // signed bin number
+                const int j = sk - a.band_start;
+                if (j >= 0 && j < a.band_count) band[j] = X.x * X.x + X.y * X.y;   // c * conj(c), quisk.c:4673
+            }
+        }
+    }
+    if (g < a.frames) {
+        double *__restrict__ avg = a.avg + (long long)g * a.N + (long long)k1 * 4096 + t;
+        if (g < a.acc_parts) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) avg[256 * m] += acc[m];
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; m++) avg[256 * m] = acc[m];
+        }
     }
 }
 
@@ -338,18 +433,26 @@ struct ReleaseArgs {
     const double *avg; double *out; const int *k0;
     int N, N1, W, n;
     double scale;              // 20 (log10 count + log10 N + 31 log10 2)
+    int parts;                 // partial averages to add up (four-step pass B keeps one per frame group)
+    double *meter;             // S-meter accumulator: copied to out[W] and cleared (quisk.c:4728-4737 uses it on the host)
 };
 __device__ __forceinline__ double avg_at(const ReleaseArgs &a, int kk)
 {
     int k = kk + a.N / 2;
     if (k >= a.N) k -= a.N;
     const int k1 = k % a.N1, k2 = k / a.N1;
-    return a.avg[(long long)k1 * (a.N / a.N1) + k2];
+    const double *p = a.avg + (long long)k1 * (a.N / a.N1) + k2;
+    double v = p[0];
+    for (int g = 1; g < a.parts; g++) v += p[(long long)g * a.N];
+    return v;
 }
-__global__ __launch_bounds__(256) void k_graph_release(ReleaseArgs a)
+// Sixteen pixels per workgroup: with zoom 1 they share the 128-byte lines of the [k1][k2] average (neighbouring k2 of one k1).
+#define REL_PIX 16
+__global__ __launch_bounds__(64 * REL_PIX) void k_graph_release(ReleaseArgs a)
 {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = blockIdx.x * REL_PIX + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.out[a.W] = *a.meter; *a.meter = 0.0; }
     if (i >= a.W) return;
     const int k0 = a.k0[i];
     double sum = 0.0;
@@ -387,6 +490,7 @@ __global__ __launch_bounds__(256) void k_graph_release_inplace(ReleaseArgs a, do
         if (threadIdx.x == 0) pix[i] = red[0];
         __syncthreads();
     }
+    if (threadIdx.x == 0) { a.out[a.W] = *a.meter; *a.meter = 0.0; }
     for (int i = threadIdx.x; i < a.W; i += 256) {
         double d = 20.0 * log10(pix[i]) - a.scale;
         if (d < -200) d = -200;
