@@ -123,6 +123,14 @@ int qk_graph_pending(qk_engine *e);
 /* Device pointer to the last released graph row (data_width doubles), for the RCCL gather. */
 int qk_graph_device(qk_engine *e, const double **dev_ptr);
 
+/* get_graph with use_fft == 0 (quisk.c:4618-4621, 4642-4649): the raw scope.  qk_set_graph_raw(1) stops the transforms and
+ * keeps, of every completed frame, the first data_width samples in a queue of four (FFT_ARRAY_SIZE, quisk.c:66); a frame
+ * that finds the queue full is dropped and counted in qk_stats.fft_error (quisk.c:2342-2345).  qk_get_graph_raw pops the
+ * oldest: writes data_width interleaved (re, im) pairs and returns 1, or returns 0 when none is waiting.  Switching modes
+ * clears the average (count_fft = 0). */
+int qk_set_graph_raw(qk_engine *e, int on);
+int qk_get_graph_raw(qk_engine *e, double *out, int data_width);
+
 /* get_multirx_graph (quisk.c:4468-4530), the transform of one sub-receiver's frame: iq_host holds
  * 8 * data_width complex samples (multirx_fft_width, quisk.c:5098); periodic Hann window (4481-4482), forward FFT,
  * 8 -> 1 magnitude binning in order of frequency and dB scaling (4491-4519) into out[data_width].  Which
@@ -174,6 +182,12 @@ enum { QK_TAP_FRONTEND = 0, QK_TAP_DECIM = 1, QK_TAP_DEMOD = 2, QK_TAP_AUDIO48 =
 int qk_debug_tap(qk_engine *e, int which, int rx, double *out_host, int cap);
 /* Statistics (debug): speculation passes the AGC kernel has run for receiver rx since creation. */
 long long qk_debug_agc_passes(qk_engine *e, int rx);
+
+/* cRxFilterOut (quisk.c:1154-1192; exported, quisk.h:215; its caller outside quisk.c is freedv.c:233) in block form: the
+ * receive band-pass of receiver rx (the taps of qk_set_filters: I taps on the real parts, Q taps on the imaginary parts,
+ * the reference's tap order) over n complex samples in host memory, with a history of its own per bank (0..2), separate
+ * from the receive chain's.  A receiver without a filter passes the samples.  Returns n. */
+int qk_rx_filter_block(qk_engine *e, int rx, int bank, const double *in_host, double *out_host, int n);
 
 /* filter.c drop-ins (filter.h:39-54) for callers that hold their samples in host memory.  The two names
  * BASELINE.json's north_star uses for them come from later Quisk releases and do not exist in this

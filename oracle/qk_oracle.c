@@ -647,6 +647,12 @@ static qko_cd rx_bandpass_real(qko_rx *rx, qko_cd s)
     return ar + I * ai;
 }
 
+void qko_rx_bandpass_block(qko_rx *rx, qko_cd *x, int n)
+{   /* cRxFilterOut (quisk.c:1154-1192) sample after sample, as freedv.c:233 calls it */
+    int i;
+    for (i = 0; i < n; i++) x[i] = rx_bandpass_iq(rx, x[i]);
+}
+
 int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
 {   /* quisk.c:1778-2014 for the modes that need no codec: CW, SSB, AM, FM, DGT-U/L/IQ/FM.
      * Off-by-default side branches (auto-notch, SSB squelch, audio measurement) are left out. */

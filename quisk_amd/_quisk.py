@@ -149,11 +149,12 @@ def add_rx_samples(samples):
         print("add_rx_samples: Invalid object sent as samples")
         return None
     unit = 2 * s.rx_bytes
-    room = MAX_PENDING - len(s.pending) // unit
-    n = len(view) // unit
-    if n > room:                                       # the reference drops what does not fit (quisk.c:2810-2812)
-        n = max(room, 0)
-    s.pending += view[:n * unit]
+    if len(view) % unit:                               # quisk.c:2798-2800: the whole buffer is dropped
+        print("add_rx_samples: Odd number of bytes in sample buffer")
+    elif len(s.pending) // unit + len(view) // unit > MAX_PENDING:      # quisk.c:2801-2803
+        print("add_rx_samples: buffer is too full")
+    else:
+        s.pending += view
     return None
 
 

@@ -177,6 +177,11 @@ struct qk_engine {
     double *d_bs_in = nullptr, *d_bs_avg = nullptr, *d_bs_out = nullptr; double2 *d_bs_X = nullptr;
     unsigned long long *d_bs_max = nullptr;
     double smeter = -160.0 + 4.25969;
+    // raw scope (get_graph with use_fft == 0, quisk.c:4642-4649): a queue of FFT_ARRAY_SIZE = 4 frame heads (quisk.c:66)
+    int raw_mode = 0, raw_head = 0, raw_count = 0;
+    double2 *d_raw_rows = nullptr;
+    // cRxFilterOut for callers outside the chain (qk_rx_filter_block): per bank [hist tap_cap][max_block] and an output block
+    double2 *d_rfb_x[3] = {nullptr, nullptr, nullptr}, *d_rfb_y = nullptr, *d_rfb_t = nullptr;
     // stats / timing
     qk_stats stats{};
     unsigned timing = 0;       // bit b: time kernel group b (QK_KT_*); bit 8: the whole block
@@ -1066,10 +1071,32 @@ static void fft_frames(qk_engine *e, const double2 *frame, int frames)
 // FFT staging (quisk.c:2324-2348): consecutive, non-overlapping frames of the PRE-mixer samples.  The reference
 // queues at most four frames for the GUI thread and drops the rest (fft_error); here every frame is
 // transformed as soon as it is complete (several at once when a block holds several).
+static int raw_frame(qk_engine *e, const double2 *frame)
+{   // the frame would be queued for the GUI thread; a full queue drops it (fft_error, quisk.c:2335-2345)
+    if (e->raw_count >= 4) { e->stats.fft_error++; return QK_OK; }
+    const int W = e->fftW, slot = (e->raw_head + e->raw_count) & 3;
+    hipLaunchKernelGGL(k_copy_c, dim3((W + 255) / 256), dim3(256), 0, e->fe_stream, frame, e->d_raw_rows + (size_t)slot * W, W);
+    e->raw_count++;
+    return QK_OK;
+}
+
 static int feed_spectrum(qk_engine *e, const double2 *x, int n)
 {
     const int N = e->fftN;
     int pos = 0;
+    if (e->raw_mode) {
+        while (pos < n) {
+            const int take = std::min(N - e->fft_fill, n - pos);
+            // only the head of a frame is ever read back: keep the first data_width samples
+            if (e->fft_fill < e->fftW) {
+                const int c = std::min(take, e->fftW - e->fft_fill);
+                HIPCHECK(hipMemcpyAsync(e->d_fft_stage + e->fft_fill, x + pos, sizeof(double2) * c, hipMemcpyDeviceToDevice, e->fe_stream));
+            }
+            e->fft_fill += take; pos += take;
+            if (e->fft_fill == N) { int rc = raw_frame(e, e->d_fft_stage); if (rc != QK_OK) return rc; e->fft_fill = 0; }
+        }
+        return QK_OK;
+    }
     while (pos < n) {
         if (e->fft_fill == 0 && n - pos >= N) {         // whole frames straight from the input block
             const int batch = e->fftN1 > 1 ? FFT_BATCH : 1;
@@ -1609,6 +1636,7 @@ void qk_destroy(qk_engine *e)
                     e->d_meter, e->d_graph, e->d_pix, e->d_k0};
     for (void *p : ptrs) if (p) hipFree(p);
     if (e->h_graph) hipHostFree(e->h_graph);
+    for (void *p : {(void *)e->d_raw_rows, (void *)e->d_rfb_x[0], (void *)e->d_rfb_x[1], (void *)e->d_rfb_x[2], (void *)e->d_rfb_y, (void *)e->d_rfb_t}) if (p) hipFree(p);
     for (auto &ev : e->ev_pool) if (ev) hipEventDestroy(ev);
     if (e->agc_stream) { hipStreamSynchronize(e->agc_stream); hipStreamDestroy(e->agc_stream); }
     if (e->apply_stream) { hipStreamSynchronize(e->apply_stream); hipStreamDestroy(e->apply_stream); }
@@ -2025,6 +2053,64 @@ int qk_get_bandscope(qk_engine *e, int clock, double zoom, double deltaf, double
     if (adc_level) { double d; memcpy(&d, &mx, sizeof d); *adc_level = d; }     // hermes_adc_level, quisk.c:4591
     e->bs_count = 0;
     return count;
+}
+
+int qk_set_graph_raw(qk_engine *e, int on)
+{
+    ENGINE_ENTER(e);
+    if (e->fftN <= 0) return fail(QK_EINVAL, "engine created without a display FFT");
+    on = on != 0;
+    if (on == e->raw_mode) return QK_OK;
+    HIPCHECK(hipStreamSynchronize(e->fe_stream));
+    if (on && !e->d_raw_rows) HIPCHECK(hipMalloc(&e->d_raw_rows, sizeof(double2) * 4 * e->fftW));
+    e->raw_mode = on; e->raw_head = e->raw_count = 0; e->fft_fill = 0;
+    e->fft_count = 0; e->fft_parts = 0;                                  // count_fft = 0, quisk.c:4618-4621
+    if (e->fftN1 <= 1) HIPCHECK(hipMemset(e->d_fft_avg, 0, sizeof(double) * e->fftN));
+    HIPCHECK(hipMemset(e->d_meter, 0, sizeof(double)));
+    return QK_OK;
+}
+
+int qk_get_graph_raw(qk_engine *e, double *out, int data_width)
+{
+    ENGINE_ENTER(e);
+    if (!e->raw_mode) return fail(QK_EINVAL, "raw scope is off (qk_set_graph_raw)");
+    if (!out || data_width != e->fftW) return fail(QK_EINVAL, "data_width differs from the engine's");
+    if (e->raw_count <= 0) return 0;
+    HIPCHECK(hipMemcpyAsync(out, e->d_raw_rows + (size_t)e->raw_head * e->fftW, sizeof(double2) * e->fftW, hipMemcpyDeviceToHost, e->fe_stream));
+    HIPCHECK(hipStreamSynchronize(e->fe_stream));
+    e->raw_head = (e->raw_head + 1) & 3; e->raw_count--;
+    return 1;
+}
+
+int qk_rx_filter_block(qk_engine *e, int rx, int bank, const double *in_host, double *out_host, int n)
+{
+    ENGINE_ENTER(e); RX_CHECK(e, rx);
+    if (bank < 0 || bank > 2 || n < 0 || n > e->cfg.max_block || (n > 0 && (!in_host || !out_host))) return fail(QK_EINVAL, "bad filter block arguments");
+    if (n == 0) return 0;
+    const int H = e->tap_cap, nt = e->ntaps[rx];
+    if (!e->d_rfb_y) {
+        HIPCHECK(hipMalloc(&e->d_rfb_y, sizeof(double2) * e->cfg.max_block));
+        HIPCHECK(hipMalloc(&e->d_rfb_t, sizeof(double2) * H));
+    }
+    if (!e->d_rfb_x[bank]) {
+        HIPCHECK(hipMalloc(&e->d_rfb_x[bank], sizeof(double2) * ((size_t)H + e->cfg.max_block)));
+        HIPCHECK(hipMemset(e->d_rfb_x[bank], 0, sizeof(double2) * H));
+    }
+    hipStream_t st = e->stream;
+    double2 *x = e->d_rfb_x[bank];
+    HIPCHECK(hipMemcpyAsync(x + H, in_host, sizeof(double2) * n, hipMemcpyHostToDevice, st));
+    if (nt > 0) {
+        const double *hI = e->d_taps + (size_t)rx * 2 * e->tap_cap;
+        hipLaunchKernelGGL(k_rxf_block, dim3((n + 255) / 256), dim3(256), 0, st, x, e->d_rfb_y, hI, hI + e->tap_cap, nt, H, n);
+        HIPCHECK(hipMemcpyAsync(out_host, e->d_rfb_y, sizeof(double2) * n, hipMemcpyDeviceToHost, st));
+    }
+    // the last H samples become the history of the next call
+    hipLaunchKernelGGL(k_copy_c, dim3((H + 255) / 256), dim3(256), 0, st, x + n, e->d_rfb_t, H);
+    hipLaunchKernelGGL(k_copy_c, dim3((H + 255) / 256), dim3(256), 0, st, e->d_rfb_t, x, H);
+    HIPCHECK(hipStreamSynchronize(st));
+    HIPCHECK(hipGetLastError());
+    if (nt <= 0) memcpy(out_host, in_host, sizeof(double2) * n);       // sizeFilter == 0: the sample passes (quisk.c:1164-1165)
+    return n;
 }
 
 int qk_get_filter_rate(int sample_rate, int mode, int bandwidth) { return filter_rate(sample_rate, mode, bandwidth); }

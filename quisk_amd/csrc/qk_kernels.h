@@ -1696,3 +1696,26 @@ __global__ __launch_bounds__(256) void k_na_scatter(const double2 *cat, const do
     if (i < n_out) samples[i] = y[i];
     if (i < nh) hist[i] = cat[count + i];           // the last nh samples of (history + block)
 }
+
+// cRxFilterOut (quisk.c:1154-1192) over a block of interleaved complex samples, for callers outside the receive chain
+// (qk_rx_filter_block): x holds H history samples followed by the n new ones; hI / hQ are the receiver's taps in the plain
+// FIR order qk_set_filters stores (h[0] = f[0], h[m] = f[N - m]): I taps on the real parts, Q taps on the imaginary parts.
+__global__ __launch_bounds__(256) void k_rxf_block(const double2 *x, double2 *y, const double *hI, const double *hQ, int ntaps, int H, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double2 *p = x + H + i;
+    double ar = 0.0, ai = 0.0;
+    for (int m = 0; m < ntaps; m++) {
+        const double2 v = p[-m];
+        ar = fma(v.x, hI[m], ar);
+        ai = fma(v.y, hQ[m], ai);
+    }
+    y[i] = make_double2(ar, ai);
+}
+// the first `w` samples of each display-spectrum frame, kept for the raw scope (get_graph with use_fft == 0, quisk.c:4642-4649)
+__global__ __launch_bounds__(256) void k_copy_c(const double2 *src, double2 *dst, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}

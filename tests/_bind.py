@@ -117,6 +117,7 @@ def oracle():
     L.qko_rx_mix.argtypes = [C.c_void_p, cdp, C.c_int]
     L.qko_rx_decimate.argtypes = [C.c_void_p, cdp, C.c_int]
     L.qko_rx_demodulate.argtypes = [C.c_void_p, cdp, ddp, C.c_int]
+    L.qko_rx_bandpass_block.argtypes = [C.c_void_p, cdp, C.c_int]
     L.qko_rx_decim_srate.argtypes = [C.c_void_p]
     L.qko_rx_filter_srate.argtypes = [C.c_void_p]
     L.qko_agc_init.argtypes = [P(OAgc), C.c_double, C.c_int]
