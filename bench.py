@@ -9,6 +9,7 @@ resident in HBM.  value = input samples processed per second (summed over ranks)
 Further legs in the same JSON line (each with its own roofline object):
   config4_slice  the per-GPU share of configs[3]: 128 mixed SSB/AM/FM receivers at 61.44 Msps, 2^20-sample blocks; with
                  N > 1 ranks the audio of all receivers is gathered to rank 0 over RCCL and that gather is timed
+  config5_slice  the per-GPU share of configs[4]: the same slice in fp32 mode with a 2^20-point FFT of every block beside it
   spectrum       configs[2]: 2^20-point windowed, averaged display FFT at 61.44 Msps (rank 0), CPU FFT timed beside it
   config1        configs[0]: 1 USB receiver at 192 ksps in 960-sample blocks, engine beside the single-threaded CPU port
   cpu_baseline   the CPU port (oracle) of the headline workload on the host cores (rank 0, N = 1 only)
@@ -53,6 +54,7 @@ def parse():
     ap.add_argument("--no-spectrum", action="store_true", help="skip the configs[2] spectrum leg")
     ap.add_argument("--no-config4", action="store_true", help="skip the configs[3] per-GPU slice leg")
     ap.add_argument("--no-config1", action="store_true", help="skip the configs[0] leg")
+    ap.add_argument("--no-config5", action="store_true", help="skip the configs[4] fp32 slice leg")
     ap.add_argument("--cpu-samples", type=int, default=1 << 21)
     return ap.parse_args()
 
@@ -400,6 +402,30 @@ def main():
             leg["gather"] = gather_outputs(eng4, nrx4)
         eng4.close()
         res["config4_slice"] = leg
+
+    # ---- configs[4] per GPU: the same slice in the engine's fp32 mode with the 2^20-point display FFT running beside it ----
+    if not a.no_config5 and block >= (1 << 20):
+        fs5, nrx5, N5 = 61440000, 128, 1 << 20
+        t5 = tune_offsets(nrx5 * world, fs5)
+        m5 = mode_mix(nrx5 * world, "mixed")
+        lo5, hi5 = receiver_slice(nrx5 * world, world, rank)
+        eng5 = make_engine(fs5, nrx5, block, local, t5[lo5:hi5], m5[lo5:hi5], fp32=True, fft_size=N5, data_width=4096)
+        k5 = min(a.steps, 100)
+        dt5, st5 = timed_leg(eng5, ptrs, block, k5, min(a.warmup, 10), barrier, (KT_FRONTEND,))
+        dt5 = max_over_ranks(dt5, torch.device("cuda", local))
+        frames5, row5, _ = eng5.get_graph(1.0, 0.0)
+        v5 = k5 * block * world / dt5 / 1e6
+        res["config5_slice"] = {
+            "workload": "per-GPU share of BASELINE configs[4]: %d mixed receivers per GPU at 61.44 Msps in fp32 mode (front end, tiled FIRs, "
+                        "FFT in float; phasor, detectors, AGC in double) with a 2^20-point windowed FFT of every block beside them" % nrx5,
+            "dtype": "f32", "value": v5, "unit": "Msamples/s", "steps": k5, "ms_per_step": dt5 / k5 * 1e3, "n_gpus": world,
+            "receivers_total": nrx5 * world, "realtime_factor": v5 * 1e6 / world / fs5,
+            "fft_frames_per_s": float(st5.fft_frames) / dt5 if dt5 > 0 else 0.0, "frames_averaged_at_the_end": int(frames5),
+            "row_finite": bool(row5 is not None and np.isfinite(row5).all()),
+            "tolerance": "tests/test_gpu_fp32.py: audio in front of the AGC <= 1e-5 relative RMS (floor 1e-8 of the stream's peak), "
+                         "spectrum <= 0.01 dB, against the fp64 oracle",
+            "roofline": frontend_roofline(st5, fs5, block, nrx5, dt5 / k5 * 1e3, True, "r02_pmc_frontend_c5.json")}
+        eng5.close()
 
     with_cpu = rank == 0 and not a.no_cpu_baseline and world == 1
     if rank == 0 and not a.no_spectrum:

@@ -52,6 +52,7 @@ struct Stage {
     StageKind kind;
     int in, out;               // stream indices within the owning chain (in == -1: the chain's input stream)
     const double *h = nullptr; // device taps (ST_FIR: permuted [D][TQP], see fir_tile)
+    const float *hf = nullptr; // ST_FIR: the same taps in float (fp32 mode)
     int T = 0, D = 1, L = 1, TQP = 0;
     int phase = 0;             // decimation counter / resampler index carried between blocks
     int rxf_kind = 0, iir_kind = 0;
@@ -82,7 +83,7 @@ struct Chain {
 };
 
 struct DevTables { std::vector<double> host; double *dev = nullptr; };
-struct FirTab { const double *hp = nullptr; int T = 0, D = 1, TQP = 0; };     // decimating FIR: permuted taps on the device
+struct FirTab { const double *hp = nullptr; const float *hpf = nullptr; int T = 0, D = 1, TQP = 0; };     // decimating FIR: permuted taps on the device
 constexpr int FT_NTH = 128, FT_R = 5;      // k_fir_tiled / k_rxf_tiled: lanes per workgroup, outputs per lane
 
 }  // namespace
@@ -113,6 +114,8 @@ struct qk_engine {
                                                        // squelch flags).  Not stats.blocks, which qk_reset_stats zeroes between blocks.
     bool agc_pending = false;
     int nrx = 0, S = 0, tap_cap = DEFAULT_TAP_CAP;
+    bool fp32 = false;         // qk_config.reserved[1]: the front end, the tiled FIRs and the display FFT compute in float
+    float *d_coefs_f = nullptr, *d_taps_f = nullptr;
     int fe_rate = 0, decim_srate = 0;
     int fe_slots = 2304;       // resident one-wave workgroups of k_frontend_wave on the whole chip (occupancy query)
     int fe_share = 100;        // percent of the resident slots the front end may occupy (QK_FE_SHARE)
@@ -296,7 +299,7 @@ struct ChainBuilder {
     {
         need_hist(cur, f.D * f.TQP + f.D);      // the tiled kernel reads whole tap chunks (zero-padded taps)
         Stage &s = add(ST_FIR, planes, cur_cap / f.D + 2);
-        s.h = f.hp; s.T = f.T; s.D = f.D; s.TQP = f.TQP; s.timer = timer;
+        s.h = f.hp; s.hf = f.hpf; s.T = f.T; s.D = f.D; s.TQP = f.TQP; s.timer = timer;
     }
     void interp(const double *h, int T, int L, int timer)
     {
@@ -617,14 +620,13 @@ static int init_receivers(qk_engine *e)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg.device) == hipSuccess) cus = prop.multiProcessorCount;
         hipError_t oe = hipErrorUnknown;
+#define QK_OCC(SS) case SS: oe = e->fp32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<SS, float>, 64, 0) \
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<SS, double>, 64, 0); break
         switch (e->S) {
-        case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<1>, 64, 0); break;
-        case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<2>, 64, 0); break;
-        case 3: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<3>, 64, 0); break;
-        case 4: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<4>, 64, 0); break;
-        case 5: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<5>, 64, 0); break;
+        QK_OCC(1); QK_OCC(2); QK_OCC(3); QK_OCC(4); QK_OCC(5);
         default: break;
         }
+#undef QK_OCC
         if (oe == hipSuccess && per_cu > 0) e->fe_slots = per_cu * cus;
     }
     e->nA = (cfg.max_block >> 12) + 2;
@@ -648,6 +650,10 @@ static int init_receivers(qk_engine *e)
     // per-receiver parameters
     HIPCHECK(hipMalloc(&e->d_taps, nrx * 2 * e->tap_cap * sizeof(double)));
     HIPCHECK(hipMemset(e->d_taps, 0, nrx * 2 * e->tap_cap * sizeof(double)));
+    if (e->fp32) {
+        HIPCHECK(hipMalloc(&e->d_taps_f, nrx * 2 * e->tap_cap * sizeof(float)));
+        HIPCHECK(hipMemset(e->d_taps_f, 0, nrx * 2 * e->tap_cap * sizeof(float)));
+    }
     HIPCHECK(hipMalloc(&e->d_ntaps, nrx * sizeof(int)));
     HIPCHECK(hipMemset(e->d_ntaps, 0, nrx * sizeof(int)));
     HIPCHECK(hipMalloc(&e->d_cls, nrx * sizeof(int)));
@@ -704,9 +710,12 @@ static int init_receivers(qk_engine *e)
     {   // the band-pass kernel stages FT_NTH * FT_R + taps doubles in dynamic LDS: above 64 KiB the launch needs the attribute
         const size_t lds = sizeof(double) * (FT_NTH * FT_R + e->tap_cap + FT_QB);
         if (lds > 160 * 1024) return fail(QK_ERANGE, "receive-filter capacity needs more LDS than a CU has");
-        if (lds > 48 * 1024)
-            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rxf_tiled<FT_NTH, FT_R>),
+        if (lds > 48 * 1024) {
+            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rxf_tiled<FT_NTH, FT_R, double>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_rxf_tiled<FT_NTH, FT_R, float>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
     }
     rc = upload_members(e);
     if (rc != QK_OK) return rc;
@@ -752,9 +761,16 @@ static int engine_init(qk_engine *e)
     HIPCHECK(hipMemcpy(e->d_coefs, T.host.data(), T.host.size() * sizeof(double), hipMemcpyHostToDevice));
 #define FIX(dst, off) e->dst = e->d_coefs + reinterpret_cast<size_t>(off)
     FIX(h_dec5, o_dec5); FIX(h_rs65, o_rs65); FIX(h_a24p4, o_a4);
+    if (e->fp32) {
+        std::vector<float> tf(T.host.begin(), T.host.end());
+        HIPCHECK(hipMalloc(&e->d_coefs_f, tf.size() * sizeof(float)));
+        HIPCHECK(hipMemcpy(e->d_coefs_f, tf.data(), tf.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     for (FirTab *f : {&e->f_dec2, &e->f_dec3, &e->f_dec5, &e->f_hbdec, &e->f_s53, &e->f_s111, &e->f_s133, &e->f_s167,
-                      &e->f_s185, &e->f_a24p3, &e->f_a24p6, &e->f_fmhp})
+                      &e->f_s185, &e->f_a24p3, &e->f_a24p6, &e->f_fmhp}) {
+        if (e->fp32) f->hpf = e->d_coefs_f + reinterpret_cast<size_t>(f->hp);
         f->hp = e->d_coefs + reinterpret_cast<size_t>(f->hp);
+    }
 #undef FIX
     int rc = QK_OK;
     {
@@ -1043,13 +1059,15 @@ static void fft_frames(qk_engine *e, const double2 *frame, int frames)
     } else if (e->fftN1 > 1) {
         const dim3 gc(e->fftN1, frames);      // N1 column tiles of 4096 / N1 columns each
         switch (e->fftN1) {
-#define QK_COLS(n1) case n1: hipLaunchKernelGGL(k_fft_cols<n1>, gc, dim3(FT16_THREADS), 0, e->fe_stream, a); break
+#define QK_COLS(n1) case n1: if (e->fp32) hipLaunchKernelGGL((k_fft_cols<n1, float2>), gc, dim3(FT16_THREADS), 0, e->fe_stream, a); \
+                             else hipLaunchKernelGGL((k_fft_cols<n1, double2>), gc, dim3(FT16_THREADS), 0, e->fe_stream, a); break
         QK_COLS(2); QK_COLS(4); QK_COLS(8); QK_COLS(16); QK_COLS(32); QK_COLS(64); QK_COLS(128); QK_COLS(256);
         QK_COLS(512); QK_COLS(1024); QK_COLS(2048); QK_COLS(4096);
 #undef QK_COLS
         }
         const int groups = std::min(frames, FFT_GROUPS);
-        hipLaunchKernelGGL(k_fft_rows, dim3(e->fftN1, groups), dim3(FT16_THREADS), 0, e->fe_stream, a);
+        if (e->fp32) hipLaunchKernelGGL(k_fft_rows<float2>, dim3(e->fftN1, groups), dim3(FT16_THREADS), 0, e->fe_stream, a);
+        else hipLaunchKernelGGL(k_fft_rows<double2>, dim3(e->fftN1, groups), dim3(FT16_THREADS), 0, e->fe_stream, a);
         e->fft_parts = std::max(e->fft_parts, groups);
     } else {
         switch (N) {
@@ -1170,17 +1188,18 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             st.phase = (st.phase + n_in) % st.D;
             out.n = n_out;
             if (n_out > 0) {
-                FirTArgs a{in.view(), out.view(), st.h, st.TQP, first, n_out, d_list};
+                const bool f32 = e->fp32 && st.hf;
+                FirTArgs a{in.view(), out.view(), f32 ? (const void *)st.hf : (const void *)st.h, st.TQP, first, n_out, d_list};
                 Timer tm(e, st.timer);
                 const dim3 grid((n_out + FT_NTH * FT_R - 1) / (FT_NTH * FT_R), in.planes, nlist);
-                const size_t lds = sizeof(double) * st.D * (FT_NTH * FT_R + st.TQP);
+                const size_t lds = (f32 ? sizeof(float) : sizeof(double)) * st.D * (FT_NTH * FT_R + st.TQP);
+#define QK_FIR(DD) case DD: if (f32) hipLaunchKernelGGL((k_fir_tiled<DD, FT_NTH, FT_R, float>), grid, dim3(FT_NTH), lds, e->stream, a); \
+                            else hipLaunchKernelGGL((k_fir_tiled<DD, FT_NTH, FT_R, double>), grid, dim3(FT_NTH), lds, e->stream, a); break
                 switch (st.D) {
-                case 1: hipLaunchKernelGGL((k_fir_tiled<1, FT_NTH, FT_R>), grid, dim3(FT_NTH), lds, e->stream, a); break;
-                case 2: hipLaunchKernelGGL((k_fir_tiled<2, FT_NTH, FT_R>), grid, dim3(FT_NTH), lds, e->stream, a); break;
-                case 3: hipLaunchKernelGGL((k_fir_tiled<3, FT_NTH, FT_R>), grid, dim3(FT_NTH), lds, e->stream, a); break;
-                case 5: hipLaunchKernelGGL((k_fir_tiled<5, FT_NTH, FT_R>), grid, dim3(FT_NTH), lds, e->stream, a); break;
+                QK_FIR(1); QK_FIR(2); QK_FIR(3); QK_FIR(5);
                 default: return fail(QK_EINVAL, "internal: FIR decimation factor without a kernel");
                 }
+#undef QK_FIR
             }
             break;
         }
@@ -1218,13 +1237,15 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         case ST_RXF: {
             out.n = n_in;
             if (n_in > 0) {
-                RxfArgs a{in.view(), out.view(), e->d_taps, e->d_ntaps, e->d_mode, e->tap_cap, n_in, st.rxf_kind, d_list};
+                RxfArgs a{in.view(), out.view(), e->fp32 ? (const void *)e->d_taps_f : (const void *)e->d_taps, e->d_ntaps, e->d_mode, e->tap_cap, n_in,
+                          st.rxf_kind, d_list};
                 Timer tm(e, st.timer);
                 int nmax = 0;
                 for (int r : c.members) nmax = std::max(nmax, e->ntaps[r]);
                 const int tqp = std::max(FT_QB, (nmax + FT_QB - 1) / FT_QB * FT_QB);
                 const dim3 grid((n_in + FT_NTH * FT_R - 1) / (FT_NTH * FT_R), 1, nlist);
-                hipLaunchKernelGGL((k_rxf_tiled<FT_NTH, FT_R>), grid, dim3(FT_NTH), sizeof(double) * (FT_NTH * FT_R + tqp), e->stream, a);
+                if (e->fp32) hipLaunchKernelGGL((k_rxf_tiled<FT_NTH, FT_R, float>), grid, dim3(FT_NTH), sizeof(float) * (FT_NTH * FT_R + tqp), e->stream, a);
+                else hipLaunchKernelGGL((k_rxf_tiled<FT_NTH, FT_R, double>), grid, dim3(FT_NTH), sizeof(double) * (FT_NTH * FT_R + tqp), e->stream, a);
             }
             break;
         }
@@ -1304,7 +1325,8 @@ static void launch_frontend(qk_engine *e, const FrontArgs &fa, int nspans)
     // every CU's LDS and registers to the kernels of the other two streams
     int gx = nspans;
     if (e->fe_share < 100) gx = std::max(1, std::min(nspans, (int)((long long)e->fe_slots * e->fe_share / 100 / std::max(1, e->nrx))));
-    hipLaunchKernelGGL((k_frontend_wave<S>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
+    if (e->fp32) hipLaunchKernelGGL((k_frontend_wave<S, float>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
+    else hipLaunchKernelGGL((k_frontend_wave<S, double>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
 }
 
 // NoiseBlanker (quisk.c:2322): five launches on the front end's stream
@@ -1601,10 +1623,10 @@ int qk_create(qk_engine **out, const qk_config *cfg)
         return fail(QK_EHIP, "no HIP device: the engine has no CPU path");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(QK_EINVAL, "bad device ordinal");
     if (cfg->reserved[1] != 0 && cfg->reserved[1] != 1) return fail(QK_EINVAL, "qk_config.reserved[1]: 0 = fp64, 1 = fp32 mode");
-    if (cfg->reserved[1] == 1) return fail(QK_EUNSUPPORTED, "fp32 mode is not built yet");
     qk_engine *e = new (std::nothrow) qk_engine();
     if (!e) return fail(QK_ENOMEM, "out of host memory");
     e->cfg = *cfg;
+    e->fp32 = cfg->reserved[1] == 1;
     if (cfg->reserved[0] > 0) e->tap_cap = (cfg->reserved[0] + FT_QB - 1) / FT_QB * FT_QB;   // max receive-filter taps
     int rc = engine_init(e);
     if (rc != QK_OK) { std::string keep = g_err; qk_destroy(e); g_err = keep; return rc; }
@@ -1631,7 +1653,7 @@ void qk_destroy(qk_engine *e)
     for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
     void *ptrs[] = {e->d_nb_x[0], e->d_nb_x[1], e->d_nb_mag[0], e->d_nb_mag[1], e->d_nb_p[0], e->d_nb_p[1], e->d_nb_y, e->d_nb_loc, e->d_nb_segsum,
                     e->d_nb_segbase, e->d_nb_S, e->d_nb_words, e->d_nb_any, e->d_cond, e->d_dc_seg_end, e->d_dc_seg_in, e->d_dc_state, e->d_dc_partial, e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps, e->d_cls,
-                    e->d_mode, e->d_release_gain, e->d_agc, e->d_agc_started, e->d_gains, e->d_agc_mag, e->d_sq_state, e->d_sq_partial, e->d_sq_flag, e->d_out,
+                    e->d_mode, e->d_release_gain, e->d_coefs_f, e->d_taps_f, e->d_agc, e->d_agc_started, e->d_gains, e->d_agc_mag, e->d_sq_state, e->d_sq_partial, e->d_sq_flag, e->d_out,
                     e->d_fft_stage, e->d_fft_Y, e->d_tw4096, e->d_tw_lo, e->d_tw_hi, e->d_window, e->d_fft_avg, e->d_band,
                     e->d_meter, e->d_graph, e->d_pix, e->d_k0};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -1718,6 +1740,10 @@ int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int
             hp[(size_t)e->tap_cap + m] = fq[m ? n - m : 0];
         }
         HIPCHECK(hipMemcpy(e->d_taps + (size_t)rx * 2 * e->tap_cap, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
+        if (e->d_taps_f) {
+            std::vector<float> hf(hp.begin(), hp.end());
+            HIPCHECK(hipMemcpy(e->d_taps_f + (size_t)rx * 2 * e->tap_cap, hf.data(), sizeof(float) * hf.size(), hipMemcpyHostToDevice));
+        }
     }
     e->ntaps[rx] = n; e->bandwidth[rx] = bandwidth; e->start_offset[rx] = start_offset;
     { int rcn = upload_ntaps(e, rx); if (rcn != QK_OK) return rcn; }

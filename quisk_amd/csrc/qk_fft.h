@@ -101,7 +101,7 @@ struct FftArgs {
     const double *window;      // N doubles (quisk.c:5091-5096)
     const double2 *tw4096;     // exp(-2 pi i j / 4096)
     const double2 *tw_lo, *tw_hi;   // four-step twiddles: W_N^j (j < 1024) and W_N^(1024 j)
-    double2 *Y;                // four-step intermediate [N1][4096]
+    void *Y;                   // four-step intermediate [frame][N1][4096], complex in the kernels' compute type
     double *avg;               // magnitude sum, layout [k1][k2] with k = k1 + N1 k2  (N1 = 1: natural order); four-step: [group][k1][k2]
     double *band;              // |X|^2 of the S-meter pass-band bins of this frame (quisk.c:4659-4680)
     int N, N1;
@@ -148,27 +148,44 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_small(FftArgs a)
 // would make every pass wait for prefetched rows and for stores nobody reads
 #define FT_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __device__ __forceinline__ int ft16_pad(int i) { return i + (i >> 4); }
-__device__ __forceinline__ void ft_bfly2(double2 &a, double2 &b)
+// The tile code is written once for complex double (double2: the reference's arithmetic) and complex float (float2: the
+// optional fp32 mode).  V = the vector type, FtReal<V> its scalar.
+template <class V> struct FtRealOf;
+template <> struct FtRealOf<double2> { typedef double type; };
+template <> struct FtRealOf<float2> { typedef float type; };
+template <class V> __device__ __forceinline__ V ft_mk(typename FtRealOf<V>::type x, typename FtRealOf<V>::type y) { V v; v.x = x; v.y = y; return v; }
+template <class V> __device__ __forceinline__ V ft_cmul(V a, V b) { return ft_mk<V>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <class V> __device__ __forceinline__ V ft_tw(double2 w) { typedef typename FtRealOf<V>::type T; return ft_mk<V>((T)w.x, (T)w.y); }   // table entry in the compute type
+template <class V>
+__device__ __forceinline__ void ft_bfly2(V &a, V &b)
 {
-    const double2 t = make_double2(a.x - b.x, a.y - b.y);
-    a = make_double2(a.x + b.x, a.y + b.y); b = t;
+    const V t = ft_mk<V>(a.x - b.x, a.y - b.y);
+    a = ft_mk<V>(a.x + b.x, a.y + b.y); b = t;
 }
 // forward 4-point DFT in place: (a, b, c, d) <- (y0, y1, y2, y3)
-__device__ __forceinline__ void ft_bfly4(double2 &a, double2 &b, double2 &c, double2 &d)
+template <class V>
+__device__ __forceinline__ void ft_bfly4(V &a, V &b, V &c, V &d)
 {
-    const double2 apc = make_double2(a.x + c.x, a.y + c.y), amc = make_double2(a.x - c.x, a.y - c.y);
-    const double2 bpd = make_double2(b.x + d.x, b.y + d.y), bmd = make_double2(b.x - d.x, b.y - d.y);
-    a = make_double2(apc.x + bpd.x, apc.y + bpd.y);
-    c = make_double2(apc.x - bpd.x, apc.y - bpd.y);
-    b = make_double2(amc.x + bmd.y, amc.y - bmd.x);         // amc - i bmd
-    d = make_double2(amc.x - bmd.y, amc.y + bmd.x);         // amc + i bmd
+    const V apc = ft_mk<V>(a.x + c.x, a.y + c.y), amc = ft_mk<V>(a.x - c.x, a.y - c.y);
+    const V bpd = ft_mk<V>(b.x + d.x, b.y + d.y), bmd = ft_mk<V>(b.x - d.x, b.y - d.y);
+    a = ft_mk<V>(apc.x + bpd.x, apc.y + bpd.y);
+    c = ft_mk<V>(apc.x - bpd.x, apc.y - bpd.y);
+    b = ft_mk<V>(amc.x + bmd.y, amc.y - bmd.x);         // amc - i bmd
+    d = ft_mk<V>(amc.x - bmd.y, amc.y + bmd.x);         // amc + i bmd
 }
 #define FT_C8 0.92387953251128673848    /* cos(pi/8) */
 #define FT_S8 0.38268343236508978178    /* sin(pi/8) */
 #define FT_H  0.70710678118654752440    /* sqrt(1/2) */
-__device__ __forceinline__ double2 ft_mul_h(double2 v, double cr, double ci) { return make_double2(v.x * cr - v.y * ci, v.x * ci + v.y * cr); }
+template <class V>
+__device__ __forceinline__ V ft_mul_h(V v, double cr_, double ci_)
+{
+    typedef typename FtRealOf<V>::type T;
+    const T cr = (T)cr_, ci = (T)ci_;
+    return ft_mk<V>(v.x * cr - v.y * ci, v.x * ci + v.y * cr);
+}
 // forward 16-point DFT of r[j], j = j0 + 4 j1; X[k] is left in r[(k >> 2) + 4 (k & 3)]
-__device__ __forceinline__ void ft_radix16(double2 (&r)[16])
+template <class V>
+__device__ __forceinline__ void ft_radix16(V (&r)[16])
 {
 #pragma unroll
     for (int j0 = 0; j0 < 4; j0++) ft_bfly4(r[j0], r[j0 + 4], r[j0 + 8], r[j0 + 12]);     // r[j0 + 4 k1] = sum_j1 a W4^(j1 k1)
@@ -177,7 +194,7 @@ __device__ __forceinline__ void ft_radix16(double2 (&r)[16])
     r[9] = ft_mul_h(r[9], FT_H, -FT_H);                     // 2
     r[13] = ft_mul_h(r[13], FT_S8, -FT_C8);                 // 3
     r[6] = ft_mul_h(r[6], FT_H, -FT_H);                     // 2
-    r[10] = make_double2(r[10].y, -r[10].x);                // 4: -i
+    r[10] = ft_mk<V>(r[10].y, -r[10].x);                    // 4: -i
     r[14] = ft_mul_h(r[14], -FT_H, -FT_H);                  // 6
     r[7] = ft_mul_h(r[7], FT_S8, -FT_C8);                   // 3
     r[11] = ft_mul_h(r[11], -FT_H, -FT_H);                  // 6
@@ -201,15 +218,15 @@ __device__ __forceinline__ constexpr int ft_slot16(int k) { return (k >> 2) + 4 
 // The lane's operands are the tile elements t + 256 j (always: NN / 16 * S = 256); X[k] goes to tile index
 // q + S (16 p + k).  The fifteen twiddles W_NN^(p k) come from four table entries (k = 1, 2, 4, 8, loaded before the
 // butterfly) and eleven products.  FROM_REGS: operands already in r; TO_REGS: X[k] stays in r[ft_slot16(k)].
-template <int NN, bool FROM_REGS, bool TO_REGS>
-__device__ __forceinline__ void ft_pass16(double2 (&r)[16], double2 *buf, const double2 *__restrict__ tw4096)
+template <int NN, bool FROM_REGS, bool TO_REGS, class V>
+__device__ __forceinline__ void ft_pass16(V (&r)[16], V *buf, const double2 *__restrict__ tw4096)
 {
     constexpr int S = 4096 / NN, SH = FtLog2<S>::value, SUB = NN / 16;
     const int t = threadIdx.x;
     const int p = t >> SH, q = t & (S - 1);
-    double2 w1, w2, w4, w8;
+    V w1, w2, w4, w8;
     if constexpr (SUB > 1) {
-        w1 = tw4096[p * S]; w2 = tw4096[2 * p * S]; w4 = tw4096[4 * p * S]; w8 = tw4096[8 * p * S];
+        w1 = ft_tw<V>(tw4096[p * S]); w2 = ft_tw<V>(tw4096[2 * p * S]); w4 = ft_tw<V>(tw4096[4 * p * S]); w8 = ft_tw<V>(tw4096[8 * p * S]);
     }
     if constexpr (!FROM_REGS) {
         const int base = t + (t >> 4);
@@ -218,15 +235,15 @@ __device__ __forceinline__ void ft_pass16(double2 (&r)[16], double2 *buf, const 
     }
     ft_radix16(r);
     if constexpr (SUB > 1) {
-        const double2 w3 = cmul_d(w1, w2), w5 = cmul_d(w1, w4), w6 = cmul_d(w2, w4), w7 = cmul_d(w3, w4);
-        r[ft_slot16(1)] = cmul_d(r[ft_slot16(1)], w1);   r[ft_slot16(2)] = cmul_d(r[ft_slot16(2)], w2);
-        r[ft_slot16(3)] = cmul_d(r[ft_slot16(3)], w3);   r[ft_slot16(4)] = cmul_d(r[ft_slot16(4)], w4);
-        r[ft_slot16(5)] = cmul_d(r[ft_slot16(5)], w5);   r[ft_slot16(6)] = cmul_d(r[ft_slot16(6)], w6);
-        r[ft_slot16(7)] = cmul_d(r[ft_slot16(7)], w7);   r[ft_slot16(8)] = cmul_d(r[ft_slot16(8)], w8);
-        r[ft_slot16(9)] = cmul_d(r[ft_slot16(9)], cmul_d(w1, w8));    r[ft_slot16(10)] = cmul_d(r[ft_slot16(10)], cmul_d(w2, w8));
-        r[ft_slot16(11)] = cmul_d(r[ft_slot16(11)], cmul_d(w3, w8));  r[ft_slot16(12)] = cmul_d(r[ft_slot16(12)], cmul_d(w4, w8));
-        r[ft_slot16(13)] = cmul_d(r[ft_slot16(13)], cmul_d(w5, w8));  r[ft_slot16(14)] = cmul_d(r[ft_slot16(14)], cmul_d(w6, w8));
-        r[ft_slot16(15)] = cmul_d(r[ft_slot16(15)], cmul_d(w7, w8));
+        const V w3 = ft_cmul(w1, w2), w5 = ft_cmul(w1, w4), w6 = ft_cmul(w2, w4), w7 = ft_cmul(w3, w4);
+        r[ft_slot16(1)] = ft_cmul(r[ft_slot16(1)], w1);   r[ft_slot16(2)] = ft_cmul(r[ft_slot16(2)], w2);
+        r[ft_slot16(3)] = ft_cmul(r[ft_slot16(3)], w3);   r[ft_slot16(4)] = ft_cmul(r[ft_slot16(4)], w4);
+        r[ft_slot16(5)] = ft_cmul(r[ft_slot16(5)], w5);   r[ft_slot16(6)] = ft_cmul(r[ft_slot16(6)], w6);
+        r[ft_slot16(7)] = ft_cmul(r[ft_slot16(7)], w7);   r[ft_slot16(8)] = ft_cmul(r[ft_slot16(8)], w8);
+        r[ft_slot16(9)] = ft_cmul(r[ft_slot16(9)], ft_cmul(w1, w8));    r[ft_slot16(10)] = ft_cmul(r[ft_slot16(10)], ft_cmul(w2, w8));
+        r[ft_slot16(11)] = ft_cmul(r[ft_slot16(11)], ft_cmul(w3, w8));  r[ft_slot16(12)] = ft_cmul(r[ft_slot16(12)], ft_cmul(w4, w8));
+        r[ft_slot16(13)] = ft_cmul(r[ft_slot16(13)], ft_cmul(w5, w8));  r[ft_slot16(14)] = ft_cmul(r[ft_slot16(14)], ft_cmul(w6, w8));
+        r[ft_slot16(15)] = ft_cmul(r[ft_slot16(15)], ft_cmul(w7, w8));
     }
     if constexpr (!TO_REGS) {
         if constexpr (!FROM_REGS) FT_BARRIER();       // every lane has read the tile before anyone overwrites it
@@ -246,8 +263,8 @@ template <int NN> __device__ __forceinline__ constexpr int ft_final_slot(int m)
     if (NN == 8) { const int u = m & 1, k = m >> 1; return u + 4 * (k & 3) + 2 * (k >> 2); }
     return m;
 }
-template <int NN, bool FROM_REGS>
-__device__ __forceinline__ void ft_final(double2 (&r)[16], double2 *buf)
+template <int NN, bool FROM_REGS, class V>
+__device__ __forceinline__ void ft_final(V (&r)[16], V *buf)
 {
     if constexpr (!FROM_REGS) {
         const int t = threadIdx.x, base = t + (t >> 4);
@@ -266,7 +283,7 @@ __device__ __forceinline__ void ft_final(double2 (&r)[16], double2 *buf)
             ft_bfly4(r[u], r[u + 4], r[u + 8], r[u + 12]);              // j0 = 0: j = 0, 2, 4, 6 -> k1 at r[u + 4 k1]
             ft_bfly4(r[u + 2], r[u + 6], r[u + 10], r[u + 14]);         // j0 = 1: j = 1, 3, 5, 7 -> k1 at r[u + 2 + 4 k1]
             r[u + 6] = ft_mul_h(r[u + 6], FT_H, -FT_H);                 // W8^1
-            r[u + 10] = make_double2(r[u + 10].y, -r[u + 10].x);        // W8^2 = -i
+            r[u + 10] = ft_mk<V>(r[u + 10].y, -r[u + 10].x);            // W8^2 = -i
             r[u + 14] = ft_mul_h(r[u + 14], -FT_H, -FT_H);              // W8^3
 #pragma unroll
             for (int k1 = 0; k1 < 4; k1++) ft_bfly2(r[u + 4 * k1], r[u + 2 + 4 * k1]);   // X[k1] at r[u + 4 k1], X[k1 + 4] at r[u + 2 + 4 k1]
@@ -277,14 +294,14 @@ __device__ __forceinline__ void ft_final(double2 (&r)[16], double2 *buf)
 // element t + 256 j.  Out: the transform's value at tile index t + 256 m (= sequence q, frequency pos, index q + S pos) is
 // r[ft_out_slot<NN>(m)].  A 4096-point row makes two trips through LDS, a 256-point column tile one, a 16-point one none.
 // The caller puts a barrier between two tiles that use the same buffer.
-template <int NN, bool FIRST = true>
-__device__ __forceinline__ void ft_run(double2 (&r)[16], double2 *buf, const double2 *__restrict__ tw4096)
+template <int NN, bool FIRST = true, class V>
+__device__ __forceinline__ void ft_run(V (&r)[16], V *buf, const double2 *__restrict__ tw4096)
 {
     if constexpr (NN >= 16) {
-        ft_pass16<NN, FIRST, NN == 16>(r, buf, tw4096);
-        if constexpr (NN > 16) ft_run<NN / 16, false>(r, buf, tw4096);
+        ft_pass16<NN, FIRST, NN == 16, V>(r, buf, tw4096);
+        if constexpr (NN > 16) ft_run<NN / 16, false, V>(r, buf, tw4096);
     } else if constexpr (NN > 1) {
-        ft_final<NN, FIRST>(r, buf);
+        ft_final<NN, FIRST, V>(r, buf);
     }
 }
 template <int NN> __device__ __forceinline__ constexpr int ft_out_slot(int m)
@@ -303,25 +320,27 @@ template <int NN> __device__ __forceinline__ constexpr int ft_out_slot(int m)
 //        g + G, ... of its row (the next one's loads in flight while this one is transformed) and adds up |X| in registers:
 //        the average is read-modified-written once per launch, not per frame.  Group g keeps its own partial average
 //        avg[g][k1][k2] (summed by the release kernel), so two workgroups per CU work on different frames of a row.
-template <int N1>
+template <int N1, class V = double2>
 __global__ __launch_bounds__(FT16_THREADS, 2) void k_fft_cols(FftArgs a)
 {
-    __shared__ __attribute__((aligned(16))) double2 buf[FT16_LDS];
+    typedef typename FtRealOf<V>::type T;
+    __shared__ __attribute__((aligned(16))) V buf[FT16_LDS];
     constexpr int TW = 4096 / N1, TSH = FtLog2<TW>::value;
     const int t = threadIdx.x, c0 = blockIdx.x * TW;
     const double2 *__restrict__ x = a.x + (long long)blockIdx.y * a.N;
-    double2 *__restrict__ Y = a.Y + (long long)blockIdx.y * a.N;
+    V *__restrict__ Y = static_cast<V *>(a.Y) + (long long)blockIdx.y * a.N;
     const double2 *__restrict__ tlo = a.tw_lo, *__restrict__ thi = a.tw_hi;
-    double2 r[16];
+    V r[16];
     if constexpr (N1 >= 16) {
         const int gb = (t >> TSH) * 4096 + c0 + (t & (TW - 1));          // x[4096 n1 + n2], n1 = (t >> TSH) + (N1 / 16) j
         const double2 wb = cmul_d(thi[gb >> 10], tlo[gb & 1023]);        // W_N^gb
+        double2 xin[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) r[j] = x[gb + j * (N1 / 16) * 4096];
+        for (int j = 0; j < 16; j++) xin[j] = x[gb + j * (N1 / 16) * 4096];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const double w = 0.5 - 0.5 * (wb.x * ft_cos16(j) + wb.y * ft_sin16(j));       // Re(wb W16^j)
-            r[j] = make_double2(r[j].x * w, r[j].y * w);
+            r[j] = ft_mk<V>((T)(xin[j].x * w), (T)(xin[j].y * w));
         }
     } else {
 #pragma unroll
@@ -331,17 +350,17 @@ __global__ __launch_bounds__(FT16_THREADS, 2) void k_fft_cols(FftArgs a)
             const double2 v = x[g];
             const double2 wh = thi[g >> 10], wl = tlo[g & 1023];
             const double w = 0.5 - 0.5 * (wh.x * wl.x - wh.y * wl.y);
-            r[m] = make_double2(v.x * w, v.y * w);
+            r[m] = ft_mk<V>((T)(v.x * w), (T)(v.y * w));
         }
     }
-    ft_run<N1>(r, buf, a.tw4096);
+    ft_run<N1, true, V>(r, buf, a.tw4096);
 #pragma unroll
     for (int m = 0; m < 16; m++) {
         const int o = t + 256 * m;
         const int k1 = o >> TSH, n2 = c0 + (o & (TW - 1));
         const int tt = n2 * k1;                                          // < N <= 2^24
         const double2 w = cmul_d(thi[tt >> 10], tlo[tt & 1023]);
-        Y[k1 * 4096 + n2] = cmul_d(r[ft_out_slot<N1>(m)], w);
+        Y[k1 * 4096 + n2] = ft_cmul(r[ft_out_slot<N1>(m)], ft_tw<V>(w));
     }
 }
 
@@ -359,17 +378,18 @@ __device__ __forceinline__ double ft_sqrt_pos(double s)
     return fma(d, h, g);
 }
 // pass B: blockIdx.x = k1, blockIdx.y = frame group
+template <class V = double2>
 __global__ __launch_bounds__(FT16_THREADS, 2) void k_fft_rows(FftArgs a)
 {
-    __shared__ __attribute__((aligned(16))) double2 buf[FT16_LDS];
+    __shared__ __attribute__((aligned(16))) V buf[FT16_LDS];
     const int t = threadIdx.x, k1 = blockIdx.x, g = blockIdx.y, G = gridDim.y;
-    const double2 *__restrict__ Yrow = a.Y + (long long)k1 * 4096 + t;
+    const V *__restrict__ Yrow = static_cast<const V *>(a.Y) + (long long)k1 * 4096 + t;
     double acc[16];
-    double2 nxt[16], r[16];
+    V nxt[16], r[16];
 #pragma unroll
     for (int m = 0; m < 16; m++) acc[m] = 0.0;
     if (g < a.frames) {
-        const double2 *__restrict__ row = Yrow + (long long)g * a.N;
+        const V *__restrict__ row = Yrow + (long long)g * a.N;
 #pragma unroll
         for (int m = 0; m < 16; m++) nxt[m] = row[256 * m];
     }
@@ -377,27 +397,27 @@ __global__ __launch_bounds__(FT16_THREADS, 2) void k_fft_rows(FftArgs a)
 #pragma unroll
         for (int m = 0; m < 16; m++) r[m] = nxt[m];
         if (f + G < a.frames) {
-            const double2 *__restrict__ row = Yrow + (long long)(f + G) * a.N;
+            const V *__restrict__ row = Yrow + (long long)(f + G) * a.N;
 #pragma unroll
             for (int m = 0; m < 16; m++) nxt[m] = row[256 * m];
         }
         if (f != g) FT_BARRIER();
-        ft_run<4096>(r, buf, a.tw4096);
+        ft_run<4096, true, V>(r, buf, a.tw4096);
         // X[k1 + N1 e], e = t + 256 k, is r[ft_slot16(k)]
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const double2 X = r[ft_slot16(k)];
-            acc[k] += ft_sqrt_pos(fma(X.x, X.x, X.y * X.y));                       // cabs, quisk.c:4707-4709; the group's frames in order
+            const double xr = (double)r[ft_slot16(k)].x, xi = (double)r[ft_slot16(k)].y;
+            acc[k] += ft_sqrt_pos(fma(xr, xr, xi * xi));                       // cabs, quisk.c:4707-4709; the group's frames in order
         }
         if (a.band_count > 0) {
             double *__restrict__ band = a.band + (long long)f * a.band_stride;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const double2 X = r[ft_slot16(k)];
+                const double xr = (double)r[ft_slot16(k)].x, xi = (double)r[ft_slot16(k)].y;
                 const int kk = k1 + a.N1 * (t + 256 * k);
                 const int sk = kk < a.N / 2 ? kk : kk - a.N;             // signed bin number
                 const int j = sk - a.band_start;
-                if (j >= 0 && j < a.band_count) band[j] = X.x * X.x + X.y * X.y;   // c * conj(c), quisk.c:4673
+                if (j >= 0 && j < a.band_count) band[j] = xr * xr + xi * xi;   // c * conj(c), quisk.c:4673
             }
         }
     }

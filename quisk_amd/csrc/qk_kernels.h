@@ -38,6 +38,13 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
+// Compute type of the FIR kernels: double (the reference's arithmetic) or float (the optional fp32 mode of BASELINE
+// configs[4]: fp32 samples, taps and accumulators inside the front end and the tiled FIRs; the mixer phasor, the streams
+// in HBM and everything behind the filters stay double).
+template <class T> struct QkVec2;
+template <> struct QkVec2<double> { typedef double2 type; };
+template <> struct QkVec2<float> { typedef float2 type; };
+
 // The 12 half-band constants (filter.c:359-362).
 #define HB_C0 0.000018566625444266
 #define HB_C1 -0.000118469698701817
@@ -154,24 +161,26 @@ struct FwLayout {
     static __host__ __device__ constexpr int R(int s) { return s == 0 ? 6 : s == 1 ? 3 : s == 2 ? 2 : 1; }
     static __host__ __device__ constexpr int warm(int S) { return ((44 << S) + 63) / 64 * 64; }
 };
-__device__ __forceinline__ double *fw_arr(double *smem, int s, int plane, int phase)
+template <class T>
+__device__ __forceinline__ T *fw_arr(T *smem, int s, int plane, int phase)
 {
     return smem + FwLayout::level_off(s) + (plane * 2 + phase) * FwLayout::sub(s);
 }
 
-template <int R>
-__device__ __forceinline__ void hb45_out(const double *__restrict__ O, const double *__restrict__ E, int m0, double (&y)[R])
+template <class T, int R>
+__device__ __forceinline__ void hb45_out(const T *__restrict__ O, const T *__restrict__ E, int m0, T (&y)[R])
 {
     // o[j] = O[m0 + 2 + j] (odd-phase samples m0-21 .. m0+R-1), e[r] = E[m0 + 12 + r] (even-phase sample m0+r-10)
-    double o[R + 22];
-    double e[R + 1];
-    if constexpr (R % 2 == 0) {         // m0 even: 16-byte vector reads
-        const double2 *po = reinterpret_cast<const double2 *>(__builtin_assume_aligned(O, 16)) + (m0 / 2 + 1);
+    typedef typename QkVec2<T>::type V2;
+    T o[R + 22];
+    T e[R + 1];
+    if constexpr (R % 2 == 0) {         // m0 even: two-element vector reads (16 bytes in double, 8 in float)
+        const V2 *po = reinterpret_cast<const V2 *>(__builtin_assume_aligned(O, sizeof(V2))) + (m0 / 2 + 1);
 #pragma unroll
-        for (int j = 0; j < (R + 22) / 2; j++) { const double2 v = po[j]; o[2 * j] = v.x; o[2 * j + 1] = v.y; }
-        const double2 *pe = reinterpret_cast<const double2 *>(__builtin_assume_aligned(E, 16)) + (m0 / 2 + 6);
+        for (int j = 0; j < (R + 22) / 2; j++) { const V2 v = po[j]; o[2 * j] = v.x; o[2 * j + 1] = v.y; }
+        const V2 *pe = reinterpret_cast<const V2 *>(__builtin_assume_aligned(E, sizeof(V2))) + (m0 / 2 + 6);
 #pragma unroll
-        for (int j = 0; j < R / 2; j++) { const double2 v = pe[j]; e[2 * j] = v.x; e[2 * j + 1] = v.y; }
+        for (int j = 0; j < R / 2; j++) { const V2 v = pe[j]; e[2 * j] = v.x; e[2 * j + 1] = v.y; }
     } else {
 #pragma unroll
         for (int j = 0; j < R + 21; j++) o[j] = O[m0 + 2 + j];
@@ -180,37 +189,38 @@ __device__ __forceinline__ void hb45_out(const double *__restrict__ O, const dou
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        double acc = (o[r + 21] + o[r]) * HB_C0;
-        acc = fma(o[r + 20] + o[r + 1], HB_C1, acc);
-        acc = fma(o[r + 19] + o[r + 2], HB_C2, acc);
-        acc = fma(o[r + 18] + o[r + 3], HB_C3, acc);
-        acc = fma(o[r + 17] + o[r + 4], HB_C4, acc);
-        acc = fma(o[r + 16] + o[r + 5], HB_C5, acc);
-        acc = fma(o[r + 15] + o[r + 6], HB_C6, acc);
-        acc = fma(o[r + 14] + o[r + 7], HB_C7, acc);
-        acc = fma(o[r + 13] + o[r + 8], HB_C8, acc);
-        acc = fma(o[r + 12] + o[r + 9], HB_C9, acc);
-        acc = fma(o[r + 11] + o[r + 10], HB_C10, acc);
-        y[r] = fma(e[r], HB_C11, acc);
+        T acc = (o[r + 21] + o[r]) * T(HB_C0);
+        acc = fma(o[r + 20] + o[r + 1], T(HB_C1), acc);
+        acc = fma(o[r + 19] + o[r + 2], T(HB_C2), acc);
+        acc = fma(o[r + 18] + o[r + 3], T(HB_C3), acc);
+        acc = fma(o[r + 17] + o[r + 4], T(HB_C4), acc);
+        acc = fma(o[r + 16] + o[r + 5], T(HB_C5), acc);
+        acc = fma(o[r + 15] + o[r + 6], T(HB_C6), acc);
+        acc = fma(o[r + 14] + o[r + 7], T(HB_C7), acc);
+        acc = fma(o[r + 13] + o[r + 8], T(HB_C8), acc);
+        acc = fma(o[r + 12] + o[r + 9], T(HB_C9), acc);
+        acc = fma(o[r + 11] + o[r + 10], T(HB_C10), acc);
+        y[r] = fma(e[r], T(HB_C11), acc);
     }
 }
 
 // carry the last 22 entries of the four polyphase arrays of level s to their front (88 doubles: lanes 0..43
 // move two each).  n_new = samples added per array this chunk.  One wave: every lane's reads are issued before
 // any lane's writes (same instruction stream, in-order LDS), so no barrier is needed even when they overlap.
-__device__ __forceinline__ void fw_carry(double *smem, int s, int n_new, int lane)
+template <class T>
+__device__ __forceinline__ void fw_carry(T *smem, int s, int n_new, int lane)
 {
     if (lane < 44) {
         const int sub = lane / 11, i = (lane % 11) * 2;         // 4 sub-arrays x 11 pairs
-        double *arr = smem + FwLayout::level_off(s) + sub * FwLayout::sub(s) + (sub & 1);
-        const double v0 = arr[n_new + i], v1 = arr[n_new + i + 1];
+        T *arr = smem + FwLayout::level_off(s) + sub * FwLayout::sub(s) + (sub & 1);
+        const T v0 = arr[n_new + i], v1 = arr[n_new + i + 1];
         arr[i] = v0; arr[i + 1] = v1;
     }
 }
 
-template <int S, int s>
-__device__ __forceinline__ void fw_stage(double *smem, int c, int lane, bool emit, double *out0, double *out1, long long obase, long long dummy,
-                                         double (&pend_y)[FwLayout::R(S - 1)], long long (&pend_i)[FwLayout::R(S - 1)])
+template <class T, int S, int s>
+__device__ __forceinline__ void fw_stage(T *smem, int c, int lane, bool emit, double *out0, double *out1, long long obase, long long dummy,
+                                         T (&pend_y)[FwLayout::R(S - 1)], long long (&pend_i)[FwLayout::R(S - 1)])
 {
     constexpr int R = FwLayout::R(s);
     const int n_out = c >> (s + 1);
@@ -220,8 +230,8 @@ __device__ __forceinline__ void fw_stage(double *smem, int c, int lane, bool emi
         // last level: every lane computes (idle lanes read padding) and hands its outputs to the chunk loop, which stores
         // them one chunk later -- real outputs to the stream, the rest to the spare slot at its end: a fixed number of
         // stores per chunk, issued in front of the next prefetch
-        double y[R];
-        hb45_out<R>(fw_arr(smem, s, plane, 1), fw_arr(smem, s, plane, 0), m0 < FW_CHUNK ? m0 : 0, y);
+        T y[R];
+        hb45_out<T, R>(fw_arr(smem, s, plane, 1), fw_arr(smem, s, plane, 0), m0 < FW_CHUNK ? m0 : 0, y);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const bool ok = emit && m0 + r < n_out;
@@ -229,14 +239,14 @@ __device__ __forceinline__ void fw_stage(double *smem, int c, int lane, bool emi
             pend_i[r] = ok ? obase + m0 + r : dummy;
         }
     } else if (m0 < n_out) {
-        double y[R];
-        hb45_out<R>(fw_arr(smem, s, plane, 1), fw_arr(smem, s, plane, 0), m0, y);
+        T y[R];
+        hb45_out<T, R>(fw_arr(smem, s, plane, 1), fw_arr(smem, s, plane, 0), m0, y);
         if constexpr (s + 1 < S) {
-            double *En = fw_arr(smem, s + 1, plane, 0), *On = fw_arr(smem, s + 1, plane, 1);
+            T *En = fw_arr(smem, s + 1, plane, 0), *On = fw_arr(smem, s + 1, plane, 1);
 #pragma unroll
             for (int r = 0; r < R; r++) {       // a partial last item spills into the arrays' padding
                 const int m = m0 + r;
-                double *d = (m & 1) ? On : En;
+                T *d = (m & 1) ? On : En;
                 d[FE_HIST + (m & 1) + (m >> 1)] = y[r];
             }
         } else {
@@ -244,21 +254,21 @@ __device__ __forceinline__ void fw_stage(double *smem, int c, int lane, bool emi
                 double *op = (plane ? out1 : out0) + obase + m0;
                 if (m0 + R <= n_out) {
 #pragma unroll
-                    for (int r = 0; r < R; r++) op[r] = y[r];
+                    for (int r = 0; r < R; r++) op[r] = (double)y[r];
                 } else {
 #pragma unroll
                     for (int r = 0; r < R; r++)
-                        if (m0 + r < n_out) op[r] = y[r];
+                        if (m0 + r < n_out) op[r] = (double)y[r];
                 }
             }
         }
     }
 }
 
-template <int S>
+template <int S, class T = double>
 __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
 {
-    __shared__ __attribute__((aligned(16))) double smem[FwLayout::total(S)];
+    __shared__ __attribute__((aligned(16))) T smem[FwLayout::total(S)];
     const int rx = blockIdx.y, lane = threadIdx.x;
     constexpr int W = FwLayout::warm(S);
     constexpr int NIT = FW_CHUNK / 64;
@@ -271,12 +281,12 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
     if (g_lo >= a.g_end) break;
     const long long g_hi = (g_lo + a.span_len < a.g_end) ? g_lo + a.span_len : a.g_end;
     __syncthreads();
-    for (int i = lane; i < FwLayout::level_off(S); i += 64) smem[i] = 0.0;
+    for (int i = lane; i < FwLayout::level_off(S); i += 64) smem[i] = T(0);
     long long pos = g_lo - W;
-    double *E0 = fw_arr(smem, 0, 0, 0), *O0 = fw_arr(smem, 0, 0, 1);
-    double *E1 = fw_arr(smem, 0, 1, 0), *O1 = fw_arr(smem, 0, 1, 1);
+    T *E0 = fw_arr(smem, 0, 0, 0), *O0 = fw_arr(smem, 0, 0, 1);
+    T *E1 = fw_arr(smem, 0, 1, 0), *O1 = fw_arr(smem, 0, 1, 1);
     // a lane's six samples of a chunk have the same parity as the lane
-    double *d0 = (lane & 1) ? O0 : E0, *d1 = (lane & 1) ? O1 : E1;
+    T *d0 = (lane & 1) ? O0 : E0, *d1 = (lane & 1) ? O1 : E1;
     const int dofs = FE_HIST + (lane & 1) + (lane >> 1);
     // The lane's mixer phasor: exact (from the tables) at its first in-block sample, then advanced by phase^64
     // from sample to sample of the lane (64 apart).  The recurrence runs over one span only (a few hundred
@@ -331,10 +341,10 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
 #define FE_PROBE(k) do { } while (0)
 #endif
     constexpr int RL = FwLayout::R(S - 1);
-    double pend_y[RL];
+    T pend_y[RL];
     long long pend_i[RL];
 #pragma unroll
-    for (int r = 0; r < RL; r++) { pend_y[r] = 0.0; pend_i[r] = dummy; }
+    for (int r = 0; r < RL; r++) { pend_y[r] = T(0); pend_i[r] = dummy; }
     double *obase_p = (lane >> 5) ? out1 : out0;
     while (pos < g_hi) {
         FE_PROBE(7);
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
             for (int it = 0; it < NIT; it++) {
                 const double2 v = cmul(xv[it], w);
                 w = cmul(w, P64);
-                d0[dofs + 32 * it] = v.x; d1[dofs + 32 * it] = v.y;
+                d0[dofs + 32 * it] = (T)v.x; d1[dofs + 32 * it] = (T)v.y;
             }
         } else {
 #pragma unroll
@@ -355,13 +365,13 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
                 if (i < c) {
                     double2 v = (okbits >> it & 1u) ? xv[it] : make_double2(0.0, 0.0);
                     if (k0 + i >= 0 && mix) { v = cmul(v, w); w = cmul(w, P64); }
-                    d0[dofs + 32 * it] = v.x; d1[dofs + 32 * it] = v.y;
+                    d0[dofs + 32 * it] = (T)v.x; d1[dofs + 32 * it] = (T)v.y;
                 }
             }
         }
         // ---- the previous chunk's outputs leave, then the next chunk's samples start their trip ----
 #pragma unroll
-        for (int r = 0; r < RL; r++) obase_p[pend_i[r]] = pend_y[r];
+        for (int r = 0; r < RL; r++) obase_p[pend_i[r]] = (double)pend_y[r];
 
         const long long npos = pos + c;
         const int nc = npos < g_hi ? chunk_len(npos) : 0;
@@ -370,18 +380,18 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
         FE_PROBE(0);
         const long long obase = (pos >> S) - a.J0;
         const bool full = c == FW_CHUNK;                 // partial chunks (warm-up tail, span end) take the safe path
-        fw_stage<S, 0>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i);
+        fw_stage<T, S, 0>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i);
         __syncthreads();
         FE_PROBE(1);
         if (full) fw_carry(smem, 0, c >> 1, lane);
-        if constexpr (S > 1) { FE_PROBE(6); fw_stage<S, 1>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(2); if (full) fw_carry(smem, 1, c >> 2, lane); }
-        if constexpr (S > 2) { FE_PROBE(6); fw_stage<S, 2>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(3); if (full) fw_carry(smem, 2, c >> 3, lane); }
-        if constexpr (S > 3) { FE_PROBE(6); fw_stage<S, 3>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(4); if (full) fw_carry(smem, 3, c >> 4, lane); }
-        if constexpr (S > 4) { FE_PROBE(6); fw_stage<S, 4>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(5); if (full) fw_carry(smem, 4, c >> 5, lane); }
+        if constexpr (S > 1) { FE_PROBE(6); fw_stage<T, S, 1>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(2); if (full) fw_carry(smem, 1, c >> 2, lane); }
+        if constexpr (S > 2) { FE_PROBE(6); fw_stage<T, S, 2>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(3); if (full) fw_carry(smem, 2, c >> 3, lane); }
+        if constexpr (S > 3) { FE_PROBE(6); fw_stage<T, S, 3>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(4); if (full) fw_carry(smem, 3, c >> 4, lane); }
+        if constexpr (S > 4) { FE_PROBE(6); fw_stage<T, S, 4>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(5); if (full) fw_carry(smem, 4, c >> 5, lane); }
         if (!full) {
             // generic carry with a barrier between the reads and the writes (source and destination may overlap)
             constexpr int NC = S * 4 * FE_HIST;
-            double keep[(NC + 63) / 64];
+            T keep[(NC + 63) / 64];
 #pragma unroll
             for (int u = 0; u < (NC + 63) / 64; u++) {
                 const int wi = lane + 64 * u;
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
         pos = npos; c = nc;
     }
 #pragma unroll
-    for (int r = 0; r < RL; r++) obase_p[pend_i[r]] = pend_y[r];
+    for (int r = 0; r < RL; r++) obase_p[pend_i[r]] = (double)pend_y[r];
 #ifdef FE_PROF
     if (lane == 0 && rx == 0 && span == 0)
         printf("fe prof: mix %lld st0 %lld st1 %lld st2 %lld st3 %lld st4 %lld carry %lld looptail %lld\n", fp[0], fp[1], fp[2], fp[3], fp[4], fp[5], fp[6], fp[7]);
@@ -430,9 +440,9 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
 // reference's k order (a different rounding order, inside the 1e-9 contract of DESIGN.md section 3).
 // ------------------------------------------------------------------------------------------------
 #define FT_QB 8
-template <int D, int NTH, int R>
-__device__ __forceinline__ void fir_tile(const double *__restrict__ x, const double *__restrict__ hp, int TQP,
-                                         int first, int jb, int t_max, double *lds, double (&acc)[R])
+template <int D, int NTH, int R, class T = double>
+__device__ __forceinline__ void fir_tile(const double *__restrict__ x, const T *__restrict__ hp, int TQP,
+                                         int first, int jb, int t_max, T *lds, T (&acc)[R])
 {
     constexpr int NO = NTH * R;
     const int LEN = NO + TQP;
@@ -441,24 +451,24 @@ __device__ __forceinline__ void fir_tile(const double *__restrict__ x, const dou
     for (int u = threadIdx.x; u < count; u += NTH) {
         const int m = u / D, s = u - m * D;
         const int t = t_lo + u;
-        lds[(D - 1 - s) * LEN + m] = t <= t_max ? x[t] : 0.0;
+        lds[(D - 1 - s) * LEN + m] = t <= t_max ? (T)x[t] : T(0);
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = 0.0;
+    for (int r = 0; r < R; r++) acc[r] = T(0);
     const int base0 = threadIdx.x * R + TQP - FT_QB;
 #pragma unroll 1
     for (int p = 0; p < D; p++) {
-        const double *xp = lds + p * LEN + base0;
-        const double *__restrict__ h = hp + p * TQP;
+        const T *xp = lds + p * LEN + base0;
+        const T *__restrict__ h = hp + p * TQP;
 #pragma unroll 1
         for (int qc = 0; qc < TQP; qc += FT_QB) {
-            double w[R + FT_QB - 1];
+            T w[R + FT_QB - 1];
 #pragma unroll
             for (int i = 0; i < R + FT_QB - 1; i++) w[i] = xp[i - qc];
 #pragma unroll
             for (int qq = 0; qq < FT_QB; qq++) {
-                const double hq = h[qc + qq];
+                const T hq = h[qc + qq];
 #pragma unroll
                 for (int r = 0; r < R; r++) acc[r] = fma(w[r + FT_QB - 1 - qq], hq, acc[r]);
             }
@@ -468,23 +478,24 @@ __device__ __forceinline__ void fir_tile(const double *__restrict__ x, const dou
 
 struct FirTArgs {
     StreamView in, out;
-    const double *hp;          // [D][TQP] permuted taps
+    const void *hp;            // [D][TQP] permuted taps, in the kernel's compute type
     int TQP, first, n_out;
     const int *rx_list;
 };
-template <int D, int NTH, int R>
+extern __shared__ __attribute__((aligned(16))) unsigned char ft_lds_raw[];
+template <int D, int NTH, int R, class T = double>
 __global__ __launch_bounds__(NTH) void k_fir_tiled(FirTArgs a)
 {
-    extern __shared__ double ft_lds[];
+    T *ft_lds = reinterpret_cast<T *>(ft_lds_raw);
     const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
     const int plane = blockIdx.y;
     const int jb = blockIdx.x * (NTH * R);
-    double acc[R];
-    fir_tile<D, NTH, R>(sv_ptr(a.in, rx, plane), a.hp, a.TQP, a.first, jb, a.first + D * (a.n_out - 1), ft_lds, acc);
+    T acc[R];
+    fir_tile<D, NTH, R, T>(sv_ptr(a.in, rx, plane), static_cast<const T *>(a.hp), a.TQP, a.first, jb, a.first + D * (a.n_out - 1), ft_lds, acc);
     double *__restrict__ o = sv_ptr(a.out, rx, plane) + jb + threadIdx.x * R;
     const int left = a.n_out - (jb + (int)threadIdx.x * R);
 #pragma unroll
-    for (int r = 0; r < R; r++) if (r < left) o[r] = acc[r];
+    for (int r = 0; r < R; r++) if (r < left) o[r] = (double)acc[r];
 }
 
 // Polyphase interpolator x L (quisk_dInterpolate / quisk_cInterpolate, filter.c:108-178):
@@ -577,34 +588,34 @@ __global__ __launch_bounds__(256) void k_fracdecim(FracArgs a)
 // ------------------------------------------------------------------------------------------------
 struct RxfArgs {
     StreamView in, out;
-    const double *taps;        // [rx][2][tap_cap]  (I taps, Q taps), in plain FIR order h[0] = f[0], h[m] = f[N - m], zero-padded
+    const void *taps;          // [rx][2][tap_cap]  (I taps, Q taps), in plain FIR order h[0] = f[0], h[m] = f[N - m], zero-padded; compute type
     const int *ntaps;          // [rx]
     const int *mode;           // [rx] rx_mode_type
     int tap_cap, n, kind;
     const int *rx_list;
 };
-template <int NTH, int R>
+template <int NTH, int R, class T = double>
 __global__ __launch_bounds__(NTH) void k_rxf_tiled(RxfArgs a)
 {
-    extern __shared__ double ft_lds[];
+    T *ft_lds = reinterpret_cast<T *>(ft_lds_raw);
     const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
     const int N = a.ntaps[rx];
     const int jb = blockIdx.x * (NTH * R), j0 = jb + threadIdx.x * R;
-    const double *__restrict__ fi = a.taps + (long long)rx * 2 * a.tap_cap;
-    const double *__restrict__ fq = (a.kind == 0) ? fi + a.tap_cap : fi;
-    double ar[R], ai[R];
+    const T *__restrict__ fi = static_cast<const T *>(a.taps) + (long long)rx * 2 * a.tap_cap;
+    const T *__restrict__ fq = (a.kind == 0) ? fi + a.tap_cap : fi;
+    T ar[R], ai[R];
     if (N == 0) {
         const double *pr = sv_ptr(a.in, rx, 0), *pi = sv_ptr(a.in, rx, 1);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const bool ok = j0 + r < a.n;
-            ar[r] = ok ? pr[j0 + r] : 0.0; ai[r] = ok ? pi[j0 + r] : 0.0;
+            ar[r] = ok ? (T)pr[j0 + r] : T(0); ai[r] = ok ? (T)pi[j0 + r] : T(0);
         }
     } else {
         const int TQP = (N + FT_QB - 1) / FT_QB * FT_QB;
-        fir_tile<1, NTH, R>(sv_ptr(a.in, rx, 0), fi, TQP, 0, jb, a.n - 1, ft_lds, ar);
+        fir_tile<1, NTH, R, T>(sv_ptr(a.in, rx, 0), fi, TQP, 0, jb, a.n - 1, ft_lds, ar);
         __syncthreads();
-        fir_tile<1, NTH, R>(sv_ptr(a.in, rx, 1), fq, TQP, 0, jb, a.n - 1, ft_lds, ai);
+        fir_tile<1, NTH, R, T>(sv_ptr(a.in, rx, 1), fq, TQP, 0, jb, a.n - 1, ft_lds, ai);
     }
     double *o0 = sv_ptr(a.out, rx, 0) + j0;
     const int left = a.n - j0;
@@ -612,14 +623,14 @@ __global__ __launch_bounds__(NTH) void k_rxf_tiled(RxfArgs a)
         const int m = a.mode[rx];
         const bool lower = (m == 0 /*CWL*/ || m == 2 /*LSB*/ || m == 8 /*DGT_L*/);
 #pragma unroll
-        for (int r = 0; r < R; r++) if (r < left) o0[r] = lower ? ar[r] + ai[r] : ar[r] - ai[r];
+        for (int r = 0; r < R; r++) if (r < left) o0[r] = (double)(lower ? ar[r] + ai[r] : ar[r] - ai[r]);
     } else if (a.kind == 1) {
 #pragma unroll
-        for (int r = 0; r < R; r++) if (r < left) o0[r] = hypot(ar[r], ai[r]);
+        for (int r = 0; r < R; r++) if (r < left) o0[r] = hypot((double)ar[r], (double)ai[r]);
     } else {
         double *o1 = sv_ptr(a.out, rx, 1) + j0;
 #pragma unroll
-        for (int r = 0; r < R; r++) if (r < left) { o0[r] = ar[r]; o1[r] = ai[r]; }
+        for (int r = 0; r < R; r++) if (r < left) { o0[r] = (double)ar[r]; o1[r] = (double)ai[r]; }
     }
 }
 
