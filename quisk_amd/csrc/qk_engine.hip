@@ -165,6 +165,7 @@ struct qk_engine {
     std::vector<int> out_count;
     // display spectrum (get_graph)
     int fftN = 0, fftN1 = 1, fftW = 0, fft_fill = 0, fft_count = 0;
+    int fft_batch = FFT_BATCH;             // frames per launch pair (QK_FFT_BATCH, 1..FFT_BATCH)
     int fft_parts = 0;                     // partial averages of the four-step row pass that hold data (0 after a release)
     double *h_graph = nullptr;             // pinned staging of a released row + the S-meter sum
     double k0_zoom = 0, k0_deltaf = 0; bool k0_valid = false;     // what d_k0 was made for
@@ -996,6 +997,7 @@ static int init_spectrum(qk_engine *e)
     if (N < 2 || N > (1 << 24)) return fail(QK_EUNSUPPORTED, "fft_size out of range (2 ... 2^24)");
     if (W < 1 || W > N) return fail(QK_EINVAL, "data_width must be in [1, fft_size]");
     const bool direct = is_pow2(N) && N >= 64;          // anything else goes through Bluestein (quisk.py:3858-3890 sizes)
+    if (const char *v = getenv("QK_FFT_BATCH")) e->fft_batch = std::max(1, std::min(FFT_BATCH, atoi(v)));
     e->fftN = N; e->fftW = W; e->fftN1 = direct && N > 4096 ? N / 4096 : 1;
     std::vector<double> win(N);
     for (int i = 0, j = -N / 2; i < N; i++, j++) win[i] = 0.5 + 0.5 * cos(2. * M_PI * j / N);   // quisk.c:5091-5096
@@ -1117,7 +1119,7 @@ static int feed_spectrum(qk_engine *e, const double2 *x, int n)
     }
     while (pos < n) {
         if (e->fft_fill == 0 && n - pos >= N) {         // whole frames straight from the input block
-            const int batch = e->fftN1 > 1 ? FFT_BATCH : 1;
+            const int batch = e->fftN1 > 1 ? e->fft_batch : 1;
             const int f = std::min(batch, (n - pos) / N);
             fft_frames(e, x + pos, f);
             pos += f * N;
