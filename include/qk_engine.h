@@ -123,6 +123,15 @@ int qk_graph_pending(qk_engine *e);
 /* Device pointer to the last released graph row (data_width doubles), for the RCCL gather. */
 int qk_graph_device(qk_engine *e, const double **dev_ptr);
 
+/* change_scan (quisk.c:3865-3872, "iidii") for hardware that sweeps its VFO: frames carry block numbers 0 .. scan_blocks-1 (the
+ * next frame after this call is block 0, then cyclically, quisk.c:3672-3689) and get_graph stitches them (quisk.c:4682-4702):
+ * of each frame the centre scan_valid part is kept, scan_blocks neighbouring bins summed into one, and ASSIGNED to the block's
+ * slot of the average; the frame count advances once per completed scan.  The S-meter window follows quisk.c:4660-4663, which
+ * reads the transmit tuning offset and vfo_screen (set_tune's second argument; change_rates): passed here.  scan_blocks = 0
+ * returns to plain averaging. */
+int qk_change_scan(qk_engine *e, int scan_blocks, int scan_sample_rate, double scan_valid, int scan_vfo0, int scan_deltaf,
+                   int tx_tune_hz, int vfo_screen);
+
 /* get_graph with use_fft == 0 (quisk.c:4618-4621, 4642-4649): the raw scope.  qk_set_graph_raw(1) stops the transforms and
  * keeps, of every completed frame, the first data_width samples in a queue of four (FFT_ARRAY_SIZE, quisk.c:66); a frame
  * that finds the queue full is dropped and counted in qk_stats.fft_error (quisk.c:2342-2345).  qk_get_graph_raw pops the

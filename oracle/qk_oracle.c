@@ -894,7 +894,15 @@ void qko_graph_init(qko_graph *g, int fft_size, int data_width, int sample_rate)
     g->avg = (double *)calloc((size_t)fft_size, sizeof(double));
     qko_hann_window(g->window, fft_size);
 }
-void qko_graph_free(qko_graph *g) { free(g->window); free(g->avg); memset(g, 0, sizeof *g); }
+void qko_graph_free(qko_graph *g) { free(g->window); free(g->avg); free(g->tmp); memset(g, 0, sizeof *g); }
+void qko_graph_change_scan(qko_graph *g, int scan_blocks, int scan_sample_rate, double scan_valid, int scan_vfo0, int scan_deltaf,
+                           int tx_tune, int vfo_screen)
+{
+    g->scan_blocks = scan_blocks; g->scan_sample_rate = scan_sample_rate; g->scan_valid = scan_valid;
+    g->scan_vfo0 = scan_vfo0; g->scan_deltaf = scan_deltaf; g->tx_tune = tx_tune; g->vfo_screen = vfo_screen;
+    g->next_block = 0;
+    if (!g->tmp) g->tmp = (double *)malloc((size_t)g->fft_size * sizeof(double));
+}
 void qko_graph_set_passband(qko_graph *g, int rx_tune, int filter_start_offset, int filter_bandwidth)
 { g->rx_tune = rx_tune; g->filter_start_offset = filter_start_offset; g->filter_bandwidth = filter_bandwidth; }
 
@@ -906,8 +914,14 @@ void qko_graph_add_frame(qko_graph *g, qko_cd *s)
     for (i = 0; i < N; i++) s[i] *= g->window[i];
     qko_fft(s, N);
     /* S-meter: power over the receive pass band, quisk.c:4659-4680 */
+    int block = 0;
+    if (g->scan_blocks) { block = g->next_block; g->next_block = block + 1 < g->scan_blocks ? block + 1 : 0; }
     d2 = (double)g->filter_bandwidth * N / g->sample_rate;
-    i = (int)((double)(g->rx_tune + g->filter_start_offset) * N / g->sample_rate + 0.5);
+    if (g->scan_blocks) {                                /* quisk.c:4660-4663 */
+        double d1 = ((double)g->tx_tune + g->vfo_screen - g->scan_vfo0 - g->scan_deltaf * block) * N / g->scan_sample_rate;
+        i = (int)(d1 - d2 / 2 + 0.5);
+    } else
+        i = (int)((double)(g->rx_tune + g->filter_start_offset) * N / g->sample_rate + 0.5);
     n = (int)(floor(d2) + 0.01);
     if (i > -N / 2 && i + n + 1 < N / 2) {
         for (j = 0; j < n; i++, j++) {
@@ -916,6 +930,23 @@ void qko_graph_add_frame(qko_graph *g, qko_cd *s)
         }
         c = i < 0 ? s[N + i] : s[i];
         g->meter = g->meter + (creal(c) * creal(c) + cimag(c) * cimag(c)) * (d2 - n);
+    }
+    if (g->scan_blocks) {                                /* quisk.c:4682-4702: the block's valid centre part, scan_blocks bins to one */
+        int m, m0, deltam, ii, nn;
+        if (block == g->scan_blocks - 1) g->count++;
+        k = 0;
+        for (i = N / 2; i < N; i++) g->tmp[k++] = cabs(s[i]);
+        for (i = 0; i < N / 2; i++) g->tmp[k++] = cabs(s[i]);
+        m0 = (int)(N * ((1.0 - g->scan_valid) / 2.0));
+        deltam = (int)(N * g->scan_valid / g->scan_blocks);
+        m = m0 + block * deltam;
+        ii = (int)(N * ((1.0 - g->scan_valid) / 2.0));
+        for (j = 0; j < deltam; j++) {
+            d2 = 0;
+            for (nn = 0; nn < g->scan_blocks; nn++) d2 += g->tmp[ii++];
+            g->avg[m++] = d2;
+        }
+        return;
     }
     /* magnitude average, negative frequencies first, quisk.c:4703-4710 */
     g->count++;

@@ -121,10 +121,17 @@ void qko_hann_window(double *w, int n);       /* quisk.c:5091-5096 */
 typedef struct {
     int fft_size, data_width, sample_rate; double *window; double *avg; int count; double meter;
     int rx_tune, filter_start_offset, filter_bandwidth;
+    /* change_scan (quisk.c:3865-3872): frames carry block numbers 0 .. scan_blocks-1 and are stitched (quisk.c:4682-4702) */
+    int scan_blocks, scan_sample_rate, scan_vfo0, scan_deltaf, tx_tune, vfo_screen, next_block;
+    double scan_valid; double *tmp;
 } qko_graph;
 void qko_graph_init(qko_graph *g, int fft_size, int data_width, int sample_rate);
 void qko_graph_free(qko_graph *g);
 void qko_graph_set_passband(qko_graph *g, int rx_tune, int filter_start_offset, int filter_bandwidth);
+/* change_scan "iidii" plus the two globals its S-meter formula reads (quisk_tx_tune_freq, vfo_screen; quisk.c:4661); the next
+ * frame is block 0 (the hardware's zero marker, quisk.c:3672-3679), later ones count up cyclically (quisk.c:3680-3689) */
+void qko_graph_change_scan(qko_graph *g, int scan_blocks, int scan_sample_rate, double scan_valid, int scan_vfo0, int scan_deltaf,
+                           int tx_tune, int vfo_screen);
 /* one filled FFT buffer: window, FFT, S-meter sum, magnitude average (quisk.c:4651-4710).  frame is overwritten. */
 void qko_graph_add_frame(qko_graph *g, qko_cd *frame);
 /* release (quisk.c:4713-4753): pixel binning, dB scaling; returns the averaged-frame count, resets the average.

@@ -181,6 +181,9 @@ struct qk_engine {
     double *d_bs_in = nullptr, *d_bs_avg = nullptr, *d_bs_out = nullptr; double2 *d_bs_X = nullptr;
     unsigned long long *d_bs_max = nullptr;
     double smeter = -160.0 + 4.25969;
+    // change_scan (quisk.c:3865-3872): frames numbered 0 .. scan_blocks-1 are stitched into d_scan_avg (order of frequency)
+    int scan_blocks = 0, scan_rate = 0, scan_vfo0 = 0, scan_deltaf = 0, scan_tx_tune = 0, scan_vfo_screen = 0, scan_next = 0;
+    double scan_valid = 0.84; double *d_scan_avg = nullptr;
     // raw scope (get_graph with use_fft == 0, quisk.c:4642-4649): a queue of FFT_ARRAY_SIZE = 4 frame heads (quisk.c:66)
     int raw_mode = 0, raw_head = 0, raw_count = 0;
     double2 *d_raw_rows = nullptr;
@@ -1049,7 +1052,18 @@ static void fft_frames(qk_engine *e, const double2 *frame, int frames)
     const int bw = e->nrx > 0 ? e->bandwidth[0] : 0;
     const int tune = e->nrx > 0 ? e->tune[0] : 0, off = e->nrx > 0 ? e->start_offset[0] : 0;
     const double d2 = (double)bw * N / fs;
-    const int i0 = (int)((double)(tune + off) * N / fs + 0.5);
+    const bool scan = e->scan_blocks > 0;
+    const int block = scan ? e->scan_next : 0;
+    if (scan) e->scan_next = block + 1 < e->scan_blocks ? block + 1 : 0;          // quisk.c:3680-3689
+    int i0 = (int)((double)(tune + off) * N / fs + 0.5);
+    if (scan) {                                                                    // quisk.c:4660-4663
+        const double d1 = ((double)e->scan_tx_tune + e->scan_vfo_screen - e->scan_vfo0 - e->scan_deltaf * block) * N / e->scan_rate;
+        i0 = (int)(d1 - d2 / 2 + 0.5);
+    }
+    if (scan) {     // the average buffers hold this one frame's magnitudes, which k_scan_stitch then places
+        a.acc_parts = 0;
+        if (e->fftN1 <= 1) hipMemsetAsync(e->d_fft_avg, 0, sizeof(double) * N, e->fe_stream);
+    }
     const int nw = (int)(floor(d2) + 0.01);
     // (a zero bandwidth adds nothing to the sum: no launch)
     const bool meter_on = bw > 0 && (i0 > -N / 2 && i0 + nw + 1 < N / 2) && nw + 1 <= e->band_cap;
@@ -1084,6 +1098,16 @@ static void fft_frames(qk_engine *e, const double2 *frame, int frames)
     }
     if (meter_on)
         hipLaunchKernelGGL(k_meter_accum, dim3(1), dim3(64), 0, e->fe_stream, e->d_band, nw, d2 - nw, e->d_meter, frames, e->band_cap);
+    if (scan) {
+        const int m0 = (int)(N * ((1.0 - e->scan_valid) / 2.0)), deltam = (int)(N * e->scan_valid / e->scan_blocks);
+        ReleaseArgs ra{e->d_fft_avg, nullptr, nullptr, N, e->fftN1, 0, 0, 0.0, 1, nullptr, 0};
+        if (deltam > 0)
+            hipLaunchKernelGGL(k_scan_stitch, dim3((deltam + 255) / 256), dim3(256), 0, e->fe_stream, ra, e->d_scan_avg, m0, deltam, block, e->scan_blocks);
+        e->fft_parts = 0;
+        if (block == e->scan_blocks - 1) e->fft_count += 1;                         // quisk.c:4683-4684
+        e->stats.fft_frames += frames;
+        return;
+    }
     e->fft_count += frames;
     e->stats.fft_frames += frames;
 }
@@ -1119,7 +1143,7 @@ static int feed_spectrum(qk_engine *e, const double2 *x, int n)
     }
     while (pos < n) {
         if (e->fft_fill == 0 && n - pos >= N) {         // whole frames straight from the input block
-            const int batch = e->fftN1 > 1 ? e->fft_batch : 1;
+            const int batch = (e->fftN1 > 1 && e->scan_blocks == 0) ? e->fft_batch : 1;
             const int f = std::min(batch, (n - pos) / N);
             fft_frames(e, x + pos, f);
             pos += f * N;
@@ -1153,14 +1177,17 @@ static int release_graph(qk_engine *e, double zoom, double deltaf, double *out, 
         HIPCHECK(hipMemcpy(e->d_k0, k0.data(), sizeof(int) * W, hipMemcpyHostToDevice));
         e->k0_valid = true; e->k0_zoom = zoom; e->k0_deltaf = deltaf;
     }
-    ReleaseArgs ra{e->d_fft_avg, e->d_graph, e->d_k0, N, e->fftN1, W, n,
+    const bool scan = e->scan_blocks > 0;
+    ReleaseArgs ra{scan ? e->d_scan_avg : e->d_fft_avg, e->d_graph, e->d_k0, N, e->fftN1, W, n,
                    20.0 * (log10((double)count) + log10((double)N) + 31.0 * log10(2.0)),          // quisk.c:4741-4742
-                   e->fftN1 > 1 ? std::max(1, e->fft_parts) : 1, e->d_meter};
+                   (e->fftN1 > 1 && !scan) ? std::max(1, e->fft_parts) : 1, e->d_meter, scan ? 1 : 0};
     if (alias) hipLaunchKernelGGL(k_graph_release_inplace, dim3(1), dim3(256), 0, e->fe_stream, ra, e->d_pix);
     else hipLaunchKernelGGL(k_graph_release, dim3((W + REL_PIX - 1) / REL_PIX), dim3(64 * REL_PIX), 0, e->fe_stream, ra);
     // one copy brings the row and the S-meter sum (the kernel left it behind the row and cleared the accumulator)
     HIPCHECK(hipMemcpyAsync(e->h_graph, e->d_graph, sizeof(double) * (W + 1), hipMemcpyDeviceToHost, e->fe_stream));
-    if (e->fftN1 <= 1)      // (the four-step pass B overwrites the average when it starts a new one: no 8 N bytes of zeros)
+    if (scan)
+        HIPCHECK(hipMemsetAsync(e->d_scan_avg, 0, sizeof(double) * N, e->fe_stream));             // quisk.c:4750-4751
+    else if (e->fftN1 <= 1)      // (the four-step pass B overwrites the average when it starts a new one: no 8 N bytes of zeros)
         HIPCHECK(hipMemsetAsync(e->d_fft_avg, 0, sizeof(double) * N, e->fe_stream));
     HIPCHECK(hipStreamSynchronize(e->fe_stream));
     memcpy(out, e->h_graph, sizeof(double) * W);
@@ -1660,7 +1687,7 @@ void qk_destroy(qk_engine *e)
                     e->d_meter, e->d_graph, e->d_pix, e->d_k0};
     for (void *p : ptrs) if (p) hipFree(p);
     if (e->h_graph) hipHostFree(e->h_graph);
-    for (void *p : {(void *)e->d_raw_rows, (void *)e->d_rfb_x[0], (void *)e->d_rfb_x[1], (void *)e->d_rfb_x[2], (void *)e->d_rfb_y, (void *)e->d_rfb_t}) if (p) hipFree(p);
+    for (void *p : {(void *)e->d_scan_avg, (void *)e->d_raw_rows, (void *)e->d_rfb_x[0], (void *)e->d_rfb_x[1], (void *)e->d_rfb_x[2], (void *)e->d_rfb_y, (void *)e->d_rfb_t}) if (p) hipFree(p);
     for (auto &ev : e->ev_pool) if (ev) hipEventDestroy(ev);
     if (e->agc_stream) { hipStreamSynchronize(e->agc_stream); hipStreamDestroy(e->agc_stream); }
     if (e->apply_stream) { hipStreamSynchronize(e->apply_stream); hipStreamDestroy(e->apply_stream); }
@@ -2081,6 +2108,23 @@ int qk_get_bandscope(qk_engine *e, int clock, double zoom, double deltaf, double
     if (adc_level) { double d; memcpy(&d, &mx, sizeof d); *adc_level = d; }     // hermes_adc_level, quisk.c:4591
     e->bs_count = 0;
     return count;
+}
+
+int qk_change_scan(qk_engine *e, int scan_blocks, int scan_sample_rate, double scan_valid, int scan_vfo0, int scan_deltaf,
+                   int tx_tune_hz, int vfo_screen)
+{
+    ENGINE_ENTER(e);
+    if (e->fftN <= 0) return fail(QK_EINVAL, "engine created without a display FFT");
+    if (scan_blocks < 0 || (scan_blocks > 0 && (scan_sample_rate <= 0 || !(scan_valid > 0) || scan_valid > 1)))
+        return fail(QK_EINVAL, "bad scan parameters");
+    HIPCHECK(hipStreamSynchronize(e->fe_stream));
+    if (scan_blocks > 0 && !e->d_scan_avg) HIPCHECK(hipMalloc(&e->d_scan_avg, sizeof(double) * e->fftN));
+    if (scan_blocks > 0) HIPCHECK(hipMemset(e->d_scan_avg, 0, sizeof(double) * e->fftN));
+    if (e->fftN1 <= 1) HIPCHECK(hipMemset(e->d_fft_avg, 0, sizeof(double) * e->fftN));
+    e->scan_blocks = scan_blocks; e->scan_rate = scan_sample_rate; e->scan_valid = scan_valid; e->scan_vfo0 = scan_vfo0;
+    e->scan_deltaf = scan_deltaf; e->scan_tx_tune = tx_tune_hz; e->scan_vfo_screen = vfo_screen; e->scan_next = 0;
+    e->fft_count = 0; e->fft_parts = 0;
+    return QK_OK;
 }
 
 int qk_set_graph_raw(qk_engine *e, int on)

@@ -455,9 +455,11 @@ struct ReleaseArgs {
     double scale;              // 20 (log10 count + log10 N + 31 log10 2)
     int parts;                 // partial averages to add up (four-step pass B keeps one per frame group)
     double *meter;             // S-meter accumulator: copied to out[W] and cleared (quisk.c:4728-4737 uses it on the host)
+    int shifted;               // 1: avg is the stitched scan average, already in order of frequency (index = kk)
 };
 __device__ __forceinline__ double avg_at(const ReleaseArgs &a, int kk)
 {
+    if (a.shifted) return a.avg[kk];
     int k = kk + a.N / 2;
     if (k >= a.N) k -= a.N;
     const int k1 = k % a.N1, k2 = k / a.N1;
@@ -466,6 +468,18 @@ __device__ __forceinline__ double avg_at(const ReleaseArgs &a, int kk)
     for (int g = 1; g < a.parts; g++) v += p[(long long)g * a.N];
     return v;
 }
+// Scan stitching (change_scan; quisk.c:4682-4702): the frame of block b contributes its valid centre part, scan_blocks
+// neighbouring bins summed into one, to positions m0 + b deltam ... of the stitched average (assigned, not added).
+// `a` describes the magnitudes of this one frame (the average buffers hold nothing else in scan mode).
+__global__ __launch_bounds__(256) void k_scan_stitch(ReleaseArgs a, double *scan_avg, int m0, int deltam, int block, int scan_blocks)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= deltam) return;
+    double d = 0.0;
+    for (int n = 0; n < scan_blocks; n++) d += avg_at(a, m0 + j * scan_blocks + n);
+    scan_avg[m0 + block * deltam + j] = d;
+}
+
 // Sixteen pixels per workgroup: with zoom 1 they share the 128-byte lines of the [k1][k2] average (neighbouring k2 of one k1).
 #define REL_PIX 16
 __global__ __launch_bounds__(64 * REL_PIX) void k_graph_release(ReleaseArgs a)

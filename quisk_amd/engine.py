@@ -60,6 +60,10 @@ def lib():
     L.qk_audio_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.qk_get_graph.argtypes = [vp, C.c_double, C.c_double, vp, C.c_int, dp]
     L.qk_graph_pending.argtypes = [vp]
+    L.qk_change_scan.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.qk_set_graph_raw.argtypes = [vp, C.c_int]
+    L.qk_get_graph_raw.argtypes = [vp, vp, C.c_int]
+    L.qk_rx_filter_block.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int]
     L.qk_set_dc_remove.argtypes = [vp, C.c_int]
     L.qk_set_invert_spectrum.argtypes = [vp, C.c_int]
     L.qk_set_noise_blanker.argtypes = [vp, C.c_int]
@@ -243,6 +247,28 @@ class Engine:
         sm = C.c_double(0.0)
         n = _check(self.L.qk_get_graph(self.h, float(zoom), float(deltaf), out.ctypes.data, self.data_width, C.byref(sm)))
         return n, out, sm.value
+
+    def change_scan(self, scan_blocks, scan_sample_rate=0, scan_valid=0.84, scan_vfo0=0, scan_deltaf=0, tx_tune=0, vfo_screen=0):
+        """change_scan (quisk.c:3865-3872): stitch the frames of a VFO sweep; scan_blocks = 0 returns to plain averaging."""
+        _check(self.L.qk_change_scan(self.h, int(scan_blocks), int(scan_sample_rate), float(scan_valid), int(scan_vfo0), int(scan_deltaf),
+                                     int(tx_tune), int(vfo_screen)))
+
+    def set_graph_raw(self, on):
+        """get_graph's use_fft == 0 mode (quisk.c:4642-4649)."""
+        _check(self.L.qk_set_graph_raw(self.h, int(bool(on))))
+
+    def get_graph_raw(self):
+        """The first data_width samples of the oldest queued frame, or None."""
+        out = np.empty(self.data_width, dtype=np.complex128)
+        n = _check(self.L.qk_get_graph_raw(self.h, out.ctypes.data, self.data_width))
+        return out if n else None
+
+    def rx_filter_block(self, rx, bank, samples):
+        """cRxFilterOut (quisk.c:1154-1192) over a block, with the history of `bank`."""
+        x = np.ascontiguousarray(samples, dtype=np.complex128)
+        out = np.empty_like(x)
+        _check(self.L.qk_rx_filter_block(self.h, int(rx), int(bank), x.ctypes.data, out.ctypes.data, len(x)))
+        return out
 
     def smeter(self):
         """get_smeter (quisk.c:2737-2742): the value of the last graph release."""

@@ -53,7 +53,9 @@ class OFrac(C.Structure):
 class OGraph(C.Structure):
     _fields_ = [("fft_size", C.c_int), ("data_width", C.c_int), ("sample_rate", C.c_int),
                 ("window", c_dp), ("avg", c_dp), ("count", C.c_int), ("meter", C.c_double),
-                ("rx_tune", C.c_int), ("filter_start_offset", C.c_int), ("filter_bandwidth", C.c_int)]
+                ("rx_tune", C.c_int), ("filter_start_offset", C.c_int), ("filter_bandwidth", C.c_int),
+                ("scan_blocks", C.c_int), ("scan_sample_rate", C.c_int), ("scan_vfo0", C.c_int), ("scan_deltaf", C.c_int),
+                ("tx_tune", C.c_int), ("vfo_screen", C.c_int), ("next_block", C.c_int), ("scan_valid", C.c_double), ("tmp", c_dp)]
 
 
 class ODcRemove(C.Structure):
@@ -143,6 +145,7 @@ def oracle():
     L.qko_graph_free.argtypes = [P(OGraph)]
     L.qko_graph_set_passband.argtypes = [P(OGraph), C.c_int, C.c_int, C.c_int]
     L.qko_graph_add_frame.argtypes = [P(OGraph), cdp]
+    L.qko_graph_change_scan.argtypes = [P(OGraph), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
     L.qko_graph_release.argtypes = [P(OGraph), C.c_double, C.c_double, ddp, P(C.c_double)]
     L.qko_rx_process_many.argtypes = [P(C.c_void_p), C.c_int, cdp, C.c_int, cdp, C.c_long, idp]
     _oracle = L
@@ -290,6 +293,9 @@ class OracleGraph:
 
     def set_passband(self, rx_tune, start_offset, bandwidth):
         self.L.qko_graph_set_passband(C.byref(self.g), int(rx_tune), int(start_offset), int(bandwidth))
+
+    def change_scan(self, blocks, rate, valid, vfo0, deltaf, tx_tune=0, vfo_screen=0):
+        self.L.qko_graph_change_scan(C.byref(self.g), int(blocks), int(rate), float(valid), int(vfo0), int(deltaf), int(tx_tune), int(vfo_screen))
 
     def add_frames(self, x):
         assert len(x) % self.N == 0

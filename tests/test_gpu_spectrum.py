@@ -107,3 +107,30 @@ def test_four_step_batched_frames(N, W):
     og.add_frames(x[8 * N:13 * N])
     assert _cmp(eng, og, zoom=0.5, deltaf=fs / 16.0) == 5
     eng.close(); og.close()
+
+
+@pytest.mark.parametrize("N,W,blocks", [(4096, 1024, 3), (16384, 2048, 4), (3000, 600, 5)])
+def test_scan_blocks_stitching(N, W, blocks):
+    """change_scan (quisk.c:3865-3872): frames numbered 0 .. scan_blocks-1 are stitched into one row (quisk.c:4682-4702) -- the
+    valid centre part of each, scan_blocks bins summed into one, assigned to the block's slot; the count advances once per
+    completed scan; the S-meter window follows quisk.c:4660-4663.  Single-workgroup, four-step and Bluestein sizes."""
+    fs = 192000
+    eng = Engine(fs, n_receivers=1, max_block=2 * N, fft_size=N, data_width=W)
+    og = B.OracleGraph(N, W, fs)
+    fi, fq, bw, off = rx_filter(fs, 3)
+    eng.set_mode(0, 3); eng.set_tune(0, 5000); eng.set_filters(0, fi, fq, bw, off)
+    og.set_passband(5000, off, bw)
+    args = (blocks, fs, 0.84, 7000000, int(fs * 0.84), 7050000 - 7100000, 7100000)     # blocks, rate, valid, vfo0, deltaf, tx tune, vfo_screen
+    eng.change_scan(*args); og.change_scan(*args)
+    nfr = 2 * blocks + 1                                      # two whole scans and the first block of a third
+    x = make_iq(nfr * N, fs, [20000, -50000, 70000], [3, 3, 4], 41)
+    eng.process(x[:N]); eng.process(x[N:N + N // 2]); eng.process(x[N + N // 2:3 * N])
+    for f in range(3, nfr):
+        eng.process(x[f * N:(f + 1) * N])
+    og.add_frames(x)
+    assert eng.graph_pending() == 2
+    assert _cmp(eng, og) == 2
+    eng.change_scan(0); og.change_scan(0, fs, 0.84, 0, 0)     # back to plain averaging
+    eng.process(x[:2 * N]); og.add_frames(x[:2 * N])
+    assert _cmp(eng, og, zoom=0.5, deltaf=1000.0) == 2
+    eng.close(); og.close()
