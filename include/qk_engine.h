@@ -82,6 +82,20 @@ int qk_set_invert_spectrum(qk_engine *e, int on);
 int qk_set_squelch(qk_engine *e, double level_db);
 int qk_squelch_active(qk_engine *e, int rx);
 int qk_set_kill_audio(qk_engine *e, int on);
+/* Second-receiver routing (quisk.c:2410-2494): the output of receiver rx becomes stereo, made of its own audio and the
+ * audio of partner_rx, both behind their own AGCs (the reference's Agc1 / Agc2, quisk.c:2563-2572), with the counts of the two
+ * equalised by Buffer2Chan's FIFOs (quisk.c:1452-1487; BUF2CHAN_SIZE scaled to the play rate).
+ *   method 1  left = rx, right = partner   (split_rxtx 1 / 2 with the receive side left; multirx_play_method 1)
+ *   method 2  left = partner, right = rx   (split_rxtx 1 / 2 with the receive side right; multirx_play_method 2)
+ *   method 3  both channels = partner      (split_rxtx 4; multirx_play_method 0)
+ *   method 0  off: mono on both channels   (also split_rxtx 3)
+ * Split RX/TX: the partner is a receiver on the same stream tuned to the transmit offset with receiver rx's mode and filter
+ * (quisk.c:2410-2418); multirx play: the sub-receiver of set_multirx_play_channel.  A squelched or killed source is silent
+ * in its own channel only (quisk.c:2585-2601).  The partner keeps its own output row. */
+int qk_set_stereo_route(qk_engine *e, int rx, int partner_rx, int method);
+/* The key went up (quisk.c:2240-2241): the next 5 ms of every receiver's output are raised along the reference's ramp
+ * (keyupEnvelope, quisk.c:2602-2612). */
+int qk_key_up(qk_engine *e);
 /* set_noise_blanker (quisk.c:4246-4252): quisk_noise_blanker, 0 = off, 1 / 2 / 3 = pulse limit 6 / 4 / 2.5 times the running
  * mean magnitude; NoiseBlanker (quisk.c:615-720) then runs behind the inversion (quisk.c:2322) and delays the stream by
  * 1.5 ms.  Switching it on starts from an empty delay line. */

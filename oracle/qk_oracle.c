@@ -987,6 +987,36 @@ int qko_graph_release(qko_graph *g, double zoom, double deltaf, double *out, dou
     return count;
 }
 
+/* ---- second-receiver routing ----------------------------------------------------------- */
+int qko_buffer2chan(qko_b2c *b, double *samp1, int count1, double *samp2, int count2)
+{   /* Buffer2Chan, quisk.c:1452-1487: the minimum of the two counts comes out, the rest waits */
+    int nout;
+    if (b->nbuf1 == 0 && b->nbuf2 == 0 && count1 == count2) return count1;
+    if (count1 + b->nbuf1 >= QKO_B2C_SIZE || count2 + b->nbuf2 >= QKO_B2C_SIZE) b->nbuf1 = b->nbuf2 = 0;
+    memcpy(b->buf1 + b->nbuf1, samp1, (size_t)count1 * sizeof(double)); b->nbuf1 += count1;
+    memcpy(b->buf2 + b->nbuf2, samp2, (size_t)count2 * sizeof(double)); b->nbuf2 += count2;
+    nout = b->nbuf1 <= b->nbuf2 ? b->nbuf1 : b->nbuf2;
+    memcpy(samp1, b->buf1, (size_t)nout * sizeof(double));
+    b->nbuf1 -= nout; memmove(b->buf1, b->buf1 + nout, (size_t)b->nbuf1 * sizeof(double));
+    memcpy(samp2, b->buf2, (size_t)nout * sizeof(double));
+    b->nbuf2 -= nout; memmove(b->buf2, b->buf2 + nout, (size_t)b->nbuf2 * sizeof(double));
+    return nout;
+}
+double qko_keyup_envelope(double env, qko_cd *x, int n, int playback_rate)
+{   /* quisk.c:2602-2612; returns the new keyupEnvelope */
+    int i;
+    double di;
+    if (env < 1.0) {
+        di = 1. / (playback_rate * 5e-3);
+        for (i = 0; i < n; i++) {
+            env += di;
+            if (env > 1.0) { env = 1.0; break; }
+            x[i] *= env;
+        }
+    }
+    return env;
+}
+
 /* ---- sub-receiver graph and bandscope ------------------------------------------------ */
 void qko_multirx_graph(qko_cd *samples, int data_width, double *out)
 {   /* get_multirx_graph, quisk.c:4478-4519; samples (8 * data_width of them) are overwritten */

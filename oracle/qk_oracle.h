@@ -138,6 +138,12 @@ void qko_graph_add_frame(qko_graph *g, qko_cd *frame);
  * out has data_width doubles; *smeter receives the S-meter value (quisk.c:4728-4737). */
 int qko_graph_release(qko_graph *g, double zoom, double deltaf, double *out, double *smeter);
 
+/* Buffer2Chan (quisk.c:1452-1487), its statics as a struct (zero-initialised); and the key-up envelope (quisk.c:2602-2612) */
+#define QKO_B2C_SIZE 12000
+typedef struct { int nbuf1, nbuf2; double buf1[QKO_B2C_SIZE], buf2[QKO_B2C_SIZE]; } qko_b2c;
+int qko_buffer2chan(qko_b2c *b, double *samp1, int count1, double *samp2, int count2);
+double qko_keyup_envelope(double env, qko_cd *x, int n, int playback_rate);
+
 /* get_multirx_graph (quisk.c:4468-4530): 8 * data_width samples (overwritten) -> data_width dB values */
 void qko_multirx_graph(qko_cd *samples, int data_width, double *out);
 /* bandscope: init_bandscope (quisk.c:2758-2775), get_bandscope (quisk.c:4532-4600) split into its two halves */

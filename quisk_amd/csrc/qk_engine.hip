@@ -163,6 +163,12 @@ struct qk_engine {
     // output
     double2 *d_out = nullptr; size_t out_stride = 0;
     std::vector<int> out_count;
+    // second-receiver routing (quisk.c:2410-2494) and Buffer2Chan's FIFOs (quisk.c:1452-1487), one per routed receiver
+    struct Route { int rx = 0, partner = 0, method = 0, nbuf_a = 0, nbuf_b = 0, cur = 0; double *fifo[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; };
+    std::vector<Route> routes; double2 *d_route_tmp = nullptr; int route_cap = 0;
+    // key-up envelope (quisk.c:2602-2612): keyupEnvelope and the pinned per-block factors the ramp kernel reads
+    double keyup_env = 1.0; double *h_keyup = nullptr; int *h_keyup_counts = nullptr; int keyup_cap = 0;
+    hipEvent_t ev_keyup = nullptr; bool keyup_used = false;
     // display spectrum (get_graph)
     int fftN = 0, fftN1 = 1, fftW = 0, fft_fill = 0, fft_count = 0;
     int fft_batch = FFT_BATCH;             // frames per launch pair (QK_FFT_BATCH, 1..FFT_BATCH)
@@ -684,6 +690,11 @@ static int init_receivers(qk_engine *e)
     e->gain_stride = (int)e->out_stride;
     HIPCHECK(hipMalloc(&e->d_out, nrx * e->out_stride * sizeof(double2)));
     HIPCHECK(hipMemset(e->d_out, 0, nrx * e->out_stride * sizeof(double2)));
+    e->route_cap = 12000 * (cfg.playback_rate / 48000);                  // BUF2CHAN_SIZE (quisk.c:1452) at the play rate
+    e->keyup_cap = (int)(cfg.playback_rate * 5e-3) + 8;
+    HIPCHECK(hipHostMalloc(&e->h_keyup, sizeof(double) * e->keyup_cap, hipHostMallocMapped));
+    HIPCHECK(hipHostMalloc(&e->h_keyup_counts, sizeof(int) * nrx, hipHostMallocMapped));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_keyup, hipEventDisableTiming));
     HIPCHECK(hipMalloc(&e->d_gains, nrx * e->gain_stride * sizeof(double)));
     HIPCHECK(hipMalloc(&e->d_agc_mag, nrx * e->gain_stride * sizeof(double)));
     if (e->apply_stream) {
@@ -1429,6 +1440,47 @@ static const double2 *condition_input(qk_engine *e, const double2 *x, int n)
     return x;
 }
 
+// Second-receiver routing and the key-up envelope (quisk.c:2410-2494, 2602-2612), queued behind k_agc_apply.
+static int output_stage(qk_engine *e, hipStream_t st)
+{
+    for (auto &r : e->routes) {
+        if (r.method <= 0) continue;
+        const int ca = e->out_count[r.rx], cb = e->out_count[r.partner];
+        if (ca + r.nbuf_a >= e->route_cap || cb + r.nbuf_b >= e->route_cap) r.nbuf_a = r.nbuf_b = 0;   // overflow: drop what waits (quisk.c:1465-1469)
+        const int ta = r.nbuf_a + ca, tb = r.nbuf_b + cb, nout = std::min(ta, tb);
+        RouteArgs a{e->d_out, (long long)e->out_stride, r.rx, r.partner, r.method, r.fifo[r.cur][0], r.fifo[r.cur][1],
+                    r.fifo[r.cur ^ 1][0], r.fifo[r.cur ^ 1][1], r.nbuf_a, r.nbuf_b, ca, cb, nout, e->d_route_tmp};
+        const int span = std::max(ta, tb);
+        if (span > 0) {
+            hipLaunchKernelGGL(k_route_mix, dim3((span + 255) / 256), dim3(256), 0, st, a);
+            if (nout > 0) hipLaunchKernelGGL(k_route_store, dim3((nout + 255) / 256), dim3(256), 0, st, a);
+        }
+        r.nbuf_a = ta - nout; r.nbuf_b = tb - nout; r.cur ^= 1;
+        e->out_count[r.rx] = nout;
+    }
+    if (e->keyup_env < 1.0) {
+        if (e->keyup_used) HIPCHECK(hipEventSynchronize(e->ev_keyup));      // the previous block's ramp kernel still reads the pinned arrays
+        int m_max = 0;
+        for (int r = 0; r < e->nrx; r++) { e->h_keyup_counts[r] = e->out_count[r]; m_max = std::max(m_max, e->out_count[r]); }
+        const double di = 1. / (e->cfg.playback_rate * 5e-3);               // 5 milliseconds
+        int nf = 0;
+        double env = e->keyup_env;
+        for (int i = 0; i < m_max && nf < e->keyup_cap; i++) {
+            env += di;
+            if (env > 1.0) { env = 1.0; break; }
+            e->h_keyup[nf++] = env;
+        }
+        e->keyup_env = env;
+        if (nf > 0) {
+            hipLaunchKernelGGL(k_keyup_ramp, dim3((nf + 255) / 256, e->nrx), dim3(256), 0, st, e->d_out, (long long)e->out_stride, e->h_keyup, nf,
+                               e->h_keyup_counts, e->nrx);
+            HIPCHECK(hipEventRecord(e->ev_keyup, st));
+            e->keyup_used = true;
+        }
+    }
+    return QK_OK;
+}
+
 static int process_device(qk_engine *e, const double2 *x, int n)
 {
     if (n < 0 || n > e->cfg.max_block) return fail(QK_ERANGE, "block larger than max_block");
@@ -1593,6 +1645,10 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             }
         }
     }
+    {   // ---- output stage behind the AGC, on the stream that wrote the output rows ----
+        int rco = output_stage(e, agc_ev_stream);
+        if (rco != QK_OK) return rco;
+    }
     HIPCHECK(hipEventRecord(e->ev_agc[par], agc_ev_stream));
     // ---- carry stream tails ----
     {
@@ -1687,6 +1743,11 @@ void qk_destroy(qk_engine *e)
                     e->d_meter, e->d_graph, e->d_pix, e->d_k0};
     for (void *p : ptrs) if (p) hipFree(p);
     if (e->h_graph) hipHostFree(e->h_graph);
+    if (e->h_keyup) hipHostFree(e->h_keyup);
+    if (e->h_keyup_counts) hipHostFree(e->h_keyup_counts);
+    if (e->ev_keyup) hipEventDestroy(e->ev_keyup);
+    if (e->d_route_tmp) hipFree(e->d_route_tmp);
+    for (auto &r : e->routes) for (auto &q : r.fifo) for (double *p : q) if (p) hipFree(p);
     for (void *p : {(void *)e->d_scan_avg, (void *)e->d_raw_rows, (void *)e->d_rfb_x[0], (void *)e->d_rfb_x[1], (void *)e->d_rfb_x[2], (void *)e->d_rfb_y, (void *)e->d_rfb_t}) if (p) hipFree(p);
     for (auto &ev : e->ev_pool) if (ev) hipEventDestroy(ev);
     if (e->agc_stream) { hipStreamSynchronize(e->agc_stream); hipStreamDestroy(e->agc_stream); }
@@ -2108,6 +2169,34 @@ int qk_get_bandscope(qk_engine *e, int clock, double zoom, double deltaf, double
     if (adc_level) { double d; memcpy(&d, &mx, sizeof d); *adc_level = d; }     // hermes_adc_level, quisk.c:4591
     e->bs_count = 0;
     return count;
+}
+
+int qk_set_stereo_route(qk_engine *e, int rx, int partner_rx, int method)
+{
+    ENGINE_ENTER(e); RX_CHECK(e, rx);
+    if (method < 0 || method > 3) return fail(QK_EINVAL, "route method must be 0..3");
+    if (method > 0) { RX_CHECK(e, partner_rx); if (partner_rx == rx) return fail(QK_EINVAL, "a receiver cannot be its own partner"); }
+    SYNC_ALL(e);
+    qk_engine::Route *rt = nullptr;
+    for (auto &r : e->routes) if (r.rx == rx) rt = &r;
+    if (!rt) {
+        if (method == 0) return QK_OK;
+        e->routes.emplace_back();
+        rt = &e->routes.back();
+        rt->rx = rx;
+        for (auto &q : rt->fifo) for (double *&p : q) HIPCHECK(hipMalloc(&p, sizeof(double) * (e->route_cap + e->out_stride)));
+    }
+    if (!e->d_route_tmp) HIPCHECK(hipMalloc(&e->d_route_tmp, sizeof(double2) * (e->route_cap + e->out_stride)));
+    if (rt->method == 0 || method == 0 || rt->partner != partner_rx) rt->nbuf_a = rt->nbuf_b = 0;      // Buffer2Chan(NULL, ...): initialise
+    rt->partner = partner_rx; rt->method = method;
+    return QK_OK;
+}
+
+int qk_key_up(qk_engine *e)
+{
+    ENGINE_ENTER(e);
+    e->keyup_env = 0.0;              // quisk.c:2241
+    return QK_OK;
 }
 
 int qk_change_scan(qk_engine *e, int scan_blocks, int scan_sample_rate, double scan_valid, int scan_vfo0, int scan_deltaf,

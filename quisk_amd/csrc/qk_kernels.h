@@ -1730,3 +1730,49 @@ __global__ __launch_bounds__(256) void k_copy_c(const double2 *src, double2 *dst
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src[i];
 }
+
+// ------------------------------------------------------------------------------------------------
+// Second-receiver routing (quisk.c:2410-2494): the audio of receiver `rx` becomes stereo, one channel its own audio and
+// the other the audio of a partner receiver (split RX/TX: the same stream tuned to the transmit frequency; or the
+// sub-receiver chosen by set_multirx_play_channel), count-equalised by the two FIFOs of Buffer2Chan (quisk.c:1452-1487).
+// Both inputs are the receivers' mono output rows behind their AGCs (the reference runs Agc1 / Agc2 on the two channels
+// separately, quisk.c:2563-2572: each channel's gain follows its own audio, as here).
+// method 1: left = rx, right = partner; 2: left = partner, right = rx; 3: both channels = partner.
+// ------------------------------------------------------------------------------------------------
+struct RouteArgs {
+    double2 *out; long long out_stride;
+    int rx, partner, method;
+    const double *fifo_a, *fifo_b;      // samples waiting from earlier blocks (a: receiver rx, b: the partner)
+    double *next_a, *next_b;            // what stays behind after this block
+    int nbuf_a, nbuf_b, ca, cb, nout;
+    double2 *tmp;
+};
+__global__ __launch_bounds__(256) void k_route_mix(RouteArgs r)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ta = r.nbuf_a + r.ca, tb = r.nbuf_b + r.cb;
+    double a = 0.0, b = 0.0;
+    if (i < ta) a = i < r.nbuf_a ? r.fifo_a[i] : r.out[(long long)r.rx * r.out_stride + (i - r.nbuf_a)].x;
+    if (i < tb) b = i < r.nbuf_b ? r.fifo_b[i] : r.out[(long long)r.partner * r.out_stride + (i - r.nbuf_b)].x;
+    if (i < r.nout) {
+        r.tmp[i] = r.method == 1 ? make_double2(a, b) : r.method == 2 ? make_double2(b, a) : make_double2(b, b);
+    } else {
+        if (i < ta) r.next_a[i - r.nout] = a;
+        if (i < tb) r.next_b[i - r.nout] = b;
+    }
+}
+__global__ __launch_bounds__(256) void k_route_store(RouteArgs r)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < r.nout) r.out[(long long)r.rx * r.out_stride + i] = r.tmp[i];
+}
+// Key-up envelope (quisk.c:2602-2612): the first samples behind a key-up are scaled by a ramp that the host has made with
+// the reference's own additions (env += 1 / (rate * 5 ms), stopping at 1); every receiver's output row gets it.
+__global__ __launch_bounds__(256) void k_keyup_ramp(double2 *out, long long out_stride, const double *factor, int nf, const int *counts_host, int n_rx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, rx = blockIdx.y;
+    if (i >= nf || i >= counts_host[rx]) return;
+    double2 v = out[(long long)rx * out_stride + i];
+    const double f = factor[i];
+    out[(long long)rx * out_stride + i] = make_double2(v.x * f, v.y * f);
+}

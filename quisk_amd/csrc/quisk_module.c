@@ -66,7 +66,10 @@ static struct {
     ty_dvoice_codec_rx dv_rx; ty_dvoice_codec_tx dv_tx;
     double *mrx_frame[QK_MAX_SUBRX]; int mrx_fill[QK_MAX_SUBRX]; int mrx_count, mrx_next;
     int rx_mode;
-} G = { .rx_bytes = 3, .rx_endian = 1, .bs_bytes = 2, .bs_endian = 1, .use_fft = 1, .graph_refresh = 7, .rx_mode = 3 };
+    /* second-receiver routing (quisk.c:2410-2494): split_rxtx 0..4, multirx_play_method 0..2, multirx_play_channel or -1 */
+    int split_rxtx, play_method, play_channel, rx_tune, tx_tune;
+    double *f0; int f0_n, f0_bw, f0_off;            /* the taps of filter slot 0, for the split partner */
+} G = { .rx_bytes = 3, .rx_endian = 1, .bs_bytes = 2, .bs_endian = 1, .use_fft = 1, .graph_refresh = 7, .rx_mode = 3, .play_channel = -1 };
 
 /* ---------------------------------------------------------------- capsule functions (quisk.h:340-349) */
 double QuiskTimeSec(void)
@@ -168,7 +171,30 @@ static void release_engine(void)
     free(G.cbuf); G.cbuf = NULL;
     free(G.row); G.row = NULL;
     G.mrx_count = G.mrx_next = 0; G.bs_size = 0;
+    free(G.f0); G.f0 = NULL; G.f0_n = 0;
+    G.split_rxtx = 0; G.play_method = 0; G.play_channel = -1;
     Py_CLEAR(G.app); Py_CLEAR(G.conf);
+}
+
+/* Which receiver is heard beside receiver 0, and in which ear (quisk.c:2410-2494).  Split RX/TX demodulates the same stream a
+ * second time at the transmit offset with receiver 0's mode and filter slot 0: the LAST receiver of the engine is kept for
+ * that.  The multirx play channel is sub-receiver 1 + index. */
+static int update_route(void)
+{
+    if (!G.qk) return QK_OK;
+    int method = 0, partner = 0;
+    if (G.split_rxtx >= 1 && G.split_rxtx <= 4 && G.nrx >= 2) {
+        partner = G.nrx - 1;
+        const int rx_left = G.split_rxtx == 1 ? G.tx_tune < G.rx_tune : G.tx_tune >= G.rx_tune;     /* quisk.c:2424, 2438 */
+        method = G.split_rxtx == 3 ? 0 : G.split_rxtx == 4 ? 3 : (rx_left ? 1 : 2);
+        if (qk_set_mode(G.qk, partner, G.rx_mode) != QK_OK) return QK_EINVAL;
+        if (qk_set_tune(G.qk, partner, G.tx_tune) != QK_OK) return QK_EINVAL;
+        if (G.f0 && qk_set_filters(G.qk, partner, G.f0, G.f0 + G.f0_n, G.f0_n, G.f0_bw, G.f0_off) != QK_OK) return QK_EINVAL;
+    } else if (G.play_channel >= 0 && 1 + G.play_channel < G.nrx) {
+        partner = 1 + G.play_channel;
+        method = G.play_method == 1 ? 1 : G.play_method == 2 ? 2 : 3;                                  /* quisk.c:2474-2493 */
+    }
+    return qk_set_stereo_route(G.qk, 0, partner, method);
 }
 
 /* ---------------------------------------------------------------- methods of the path */
@@ -313,6 +339,8 @@ static PyObject *set_tune(PyObject *self, PyObject *args)
     if (!PyArg_ParseTuple(args, "ii", &rx_hz, &tx_hz)) return NULL;
     if (!need_engine()) return NULL;
     if (qk_set_tune(G.qk, 0, rx_hz) != QK_OK) return engine_error();
+    G.rx_tune = rx_hz; G.tx_tune = tx_hz;
+    if (G.split_rxtx && update_route() != QK_OK) return engine_error();
     Py_RETURN_NONE;
 }
 static PyObject *set_rx_mode(PyObject *self, PyObject *args)
@@ -322,6 +350,36 @@ static PyObject *set_rx_mode(PyObject *self, PyObject *args)
     if (!need_engine()) return NULL;
     if (qk_set_mode(G.qk, 0, mode) != QK_OK) return engine_error();
     G.rx_mode = mode;
+    if (G.split_rxtx && update_route() != QK_OK) return engine_error();
+    Py_RETURN_NONE;
+}
+static PyObject *set_split_rxtx(PyObject *self, PyObject *args)
+{   /* quisk.c:4372-4379 */
+    if (!PyArg_ParseTuple(args, "i", &G.split_rxtx)) return NULL;
+    if (!need_engine()) return NULL;
+    if (update_route() != QK_OK) return engine_error();
+    Py_RETURN_NONE;
+}
+static PyObject *set_multirx_play_method(PyObject *self, PyObject *args)
+{   /* quisk.c:4450-4456 */
+    if (!PyArg_ParseTuple(args, "i", &G.play_method)) return NULL;
+    if (!need_engine()) return NULL;
+    if (update_route() != QK_OK) return engine_error();
+    Py_RETURN_NONE;
+}
+static PyObject *set_multirx_play_channel(PyObject *self, PyObject *args)
+{   /* quisk.c:4458-4466: -1 = none */
+    if (!PyArg_ParseTuple(args, "i", &G.play_channel)) return NULL;
+    if (G.play_channel >= QK_MAX_SUBRX) G.play_channel = -1;
+    if (!need_engine()) return NULL;
+    if (update_route() != QK_OK) return engine_error();
+    Py_RETURN_NONE;
+}
+static PyObject *key_up(PyObject *self, PyObject *args)
+{   /* an addition: the transmit side tells the receive path that the key went up (quisk.c:2240-2241) */
+    if (!PyArg_ParseTuple(args, "")) return NULL;
+    if (!need_engine()) return NULL;
+    if (qk_key_up(G.qk) != QK_OK) return engine_error();
     Py_RETURN_NONE;
 }
 
@@ -351,9 +409,15 @@ static PyObject *set_filters(PyObject *self, PyObject *args)
     }
     /* slot 0 = receiver 0, slot 1 = the sub-receivers (quisk.c:2472); slot 2 feeds the external digital path (off the path) */
     int rc = QK_OK;
-    if (nFilter == 0) rc = qk_set_filters(G.qk, 0, ti, tq, (int)size, bw, start_offset);
+    if (nFilter == 0) {
+        rc = qk_set_filters(G.qk, 0, ti, tq, (int)size, bw, start_offset);
+        free(G.f0);
+        G.f0 = malloc(sizeof(double) * 2 * (size_t)(size + 1));
+        if (G.f0) { memcpy(G.f0, ti, sizeof(double) * (size_t)size); memcpy(G.f0 + size, tq, sizeof(double) * (size_t)size); G.f0_n = (int)size; G.f0_bw = bw; G.f0_off = start_offset; }
+        if (rc == QK_OK && G.split_rxtx) rc = update_route();
+    }
     else if (nFilter == 1)
-        for (int r = 1; r < G.nrx && rc == QK_OK; r++) rc = qk_set_filters(G.qk, r, ti, tq, (int)size, bw, start_offset);
+        for (int r = 1; r < G.nrx - (G.split_rxtx ? 1 : 0) && rc == QK_OK; r++) rc = qk_set_filters(G.qk, r, ti, tq, (int)size, bw, start_offset);
     free(ti);
     if (rc != QK_OK) return engine_error();
     Py_RETURN_NONE;
@@ -596,12 +660,15 @@ static PyMethodDef QuiskMethods[] = {
     { "set_kill_audio", set_kill_audio, METH_VARARGS, "Replace radio sound with silence." },
     { "set_noise_blanker", set_noise_blanker, METH_VARARGS, "Set the noise blanker level." },
     { "set_squelch", set_squelch, METH_VARARGS, "Set the FM squelch parameter." },
+    { "set_split_rxtx", set_split_rxtx, METH_VARARGS, "Set split for rx/tx." },
+    { "set_multirx_play_method", set_multirx_play_method, METH_VARARGS, "Select how to play audio from sub-receivers." },
+    { "set_multirx_play_channel", set_multirx_play_channel, METH_VARARGS, "Select which sub-receiver to play audio." },
+    { "key_up", key_up, METH_VARARGS, "The key went up: start the 5 ms envelope." },
     { "rx_filter_block", rx_filter_block, METH_VARARGS, "cRxFilterOut over a block of complex128 samples." },
     { "is_key_down", (PyCFunction)inert_zero, METH_VARARGS | METH_KEYWORDS, "Receive only: the key is up." },
     { "get_hardware_ptt", (PyCFunction)inert_zero, METH_VARARGS | METH_KEYWORDS, "Receive only." },
     { "is_vox", (PyCFunction)inert_zero, METH_VARARGS | METH_KEYWORDS, "Receive only." },
-    INERT("set_volume"), INERT("set_ssb_squelch"), INERT("set_auto_notch"), INERT("set_split_rxtx"), INERT("set_multirx_play_method"),
-    INERT("set_multirx_play_channel"), INERT("set_enable_bandscope"), INERT("add_tone"), INERT("set_spot_level"), INERT("set_imd_level"),
+    INERT("set_volume"), INERT("set_ssb_squelch"), INERT("set_auto_notch"), INERT("set_enable_bandscope"), INERT("add_tone"), INERT("set_spot_level"), INERT("set_imd_level"),
     INERT("set_key_down"), INERT("set_PTT"), INERT("set_ctcss"), INERT("set_tx_audio"), INERT("set_record_state"), INERT("set_file_name"),
     INERT("set_sidetone"), INERT("set_transmit_mode"), INERT("set_fdx"), INERT("set_sample_bytes"), INERT("change_rate"),
     INERT("change_rates"), INERT("change_scan"), INERT("open_sound"), INERT("open_key"), INERT("open_rx_udp"), INERT("close_rx_udp"),

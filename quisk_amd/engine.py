@@ -60,6 +60,8 @@ def lib():
     L.qk_audio_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.qk_get_graph.argtypes = [vp, C.c_double, C.c_double, vp, C.c_int, dp]
     L.qk_graph_pending.argtypes = [vp]
+    L.qk_set_stereo_route.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.qk_key_up.argtypes = [vp]
     L.qk_change_scan.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
     L.qk_set_graph_raw.argtypes = [vp, C.c_int]
     L.qk_get_graph_raw.argtypes = [vp, vp, C.c_int]
@@ -180,6 +182,14 @@ class Engine:
     def set_kill_audio(self, on):
         """set_kill_audio (quisk.c:4364-4370)."""
         _check(self.L.qk_set_kill_audio(self.h, int(bool(on))))
+
+    def set_stereo_route(self, rx, partner_rx, method):
+        """Second-receiver routing (quisk.c:2410-2494): 1 = (rx, partner), 2 = (partner, rx), 3 = partner on both, 0 = off."""
+        _check(self.L.qk_set_stereo_route(self.h, int(rx), int(partner_rx), int(method)))
+
+    def key_up(self):
+        """The key went up: the 5 ms envelope of quisk.c:2602-2612 starts with the next block."""
+        _check(self.L.qk_key_up(self.h))
 
     def set_noise_blanker(self, level):
         """set_noise_blanker (quisk.c:4246-4252): 0 off, 1 / 2 / 3 = pulse limit 6 / 4 / 2.5."""

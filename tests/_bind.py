@@ -69,6 +69,10 @@ class ONoiseBlanker(C.Structure):
                 ("state", C.c_int), ("index", C.c_int), ("win_index", C.c_int), ("sample_rate", C.c_int)]
 
 
+class OB2C(C.Structure):
+    _fields_ = [("nbuf1", C.c_int), ("nbuf2", C.c_int), ("buf1", C.c_double * 12000), ("buf2", C.c_double * 12000)]
+
+
 class OBscope(C.Structure):
     _fields_ = [("size", C.c_int), ("count", C.c_int), ("window", c_dp), ("avg", c_dp), ("the_max", C.c_double)]
 
@@ -147,6 +151,9 @@ def oracle():
     L.qko_graph_add_frame.argtypes = [P(OGraph), cdp]
     L.qko_graph_change_scan.argtypes = [P(OGraph), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
     L.qko_graph_release.argtypes = [P(OGraph), C.c_double, C.c_double, ddp, P(C.c_double)]
+    L.qko_buffer2chan.argtypes = [P(OB2C), ddp, C.c_int, ddp, C.c_int]
+    L.qko_keyup_envelope.argtypes = [C.c_double, cdp, C.c_int, C.c_int]
+    L.qko_keyup_envelope.restype = C.c_double
     L.qko_rx_process_many.argtypes = [P(C.c_void_p), C.c_int, cdp, C.c_int, cdp, C.c_long, idp]
     _oracle = L
     return L

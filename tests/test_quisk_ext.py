@@ -182,3 +182,34 @@ def test_c_plugin_feeds_samples_through_the_capsule_and_exported_symbols():
     SRC.attach()
     QS.close_sound()
     assert SRC.state()[1] == 1                            # the plug-in's stop callback ran
+
+
+@pytest.mark.gpu
+def test_split_rxtx_and_multirx_play_through_the_extension():
+    """set_split_rxtx / set_multirx_play_method / set_multirx_play_channel (quisk.c:4315, 4450, 4458) reach the router:
+    the second ear carries the receiver tuned to the transmit offset, or the chosen sub-receiver (quisk.c:2410-2494)."""
+    fs, mode, rx_t, tx_t = 96000, 3, 12000, -20000
+    QS.record_app(None, _conf(quisk_amd_receivers=4), 512, 512, 2048, 64, fs, 0)
+    QS.set_params(rx_bytes=4, rx_endian=0)
+    fi, fq, bw, off = rx_filter(fs, mode)
+    QS.set_rx_mode(mode); QS.set_filters(list(fi), list(fq), bw, off, 0); QS.set_filters(list(fi), list(fq), bw, off, 1)
+    QS.set_tune(rx_t, tx_t)
+    QS.set_multirx_mode(0, mode); QS.set_multirx_freq(0, 30000)
+    t = np.arange(12 * 4800) / fs
+    x = np.round(2.0 ** 24 * (np.exp(2j * np.pi * (rx_t + 1000) * t) + np.exp(2j * np.pi * (tx_t + 700) * t) + np.exp(2j * np.pi * (30000 + 400) * t)))
+    o_rx, o_tx, o_sub = make_oracle_rx(fs, mode, rx_t), make_oracle_rx(fs, mode, tx_t), make_oracle_rx(fs, mode, 30000)
+    QS.set_split_rxtx(1)                                  # stereo, higher frequency is real: tx < rx -> left = receive side
+    for b in range(12):
+        blk = x[b * 4800:(b + 1) * 4800]
+        if b == 6:
+            QS.set_split_rxtx(0); QS.set_multirx_play_method(2); QS.set_multirx_play_channel(0)     # left = sub-receiver 0, right = receiver 0
+        QS.add_rx_samples(_raw32(blk)); QS.read_sound()
+        a, bb, c = o_rx.process(blk).real, o_tx.process(blk).real, o_sub.process(blk).real
+        got = _audio(0)
+        if b in (4, 5):
+            assert rel_err(got, a + 1j * bb) < TOL
+        if b in (10, 11):
+            assert rel_err(got, c + 1j * a) < TOL
+    for o in (o_rx, o_tx, o_sub):
+        o.close()
+    QS.close_sound()
