@@ -82,6 +82,20 @@ int qk_set_invert_spectrum(qk_engine *e, int on);
 int qk_set_squelch(qk_engine *e, double level_db);
 int qk_squelch_active(qk_engine *e, int rx);
 int qk_set_kill_audio(qk_engine *e, int on);
+/* set_ssb_squelch (quisk.c:4356-4362): ssb_squelch (quisk.c:1022-1116) on the detected audio of LSB / USB / AM receivers --
+ * frames of 512 samples, Hann window, transform; the arithmetic over the geometric mean of the power in 300 Hz .. 300 Hz +
+ * min(bandwidth, 3000) opens the squelch for one second when its logarithm exceeds level * 0.005; the audio is delayed by
+ * one frame (d_delay, quisk.c:993-1020) and muted behind the AGC while the squelch is closed.  A receiver's first block
+ * after creation is not analysed (the reference's first call only builds its plan).  qk_squelch_active reports it.
+ * set_auto_notch (quisk.c:4237-4244; dAutoNotch, quisk.c:730-899) per receiver (the reference runs it on bank 0 only): the
+ * audio passes an overlap-save filter of 2048-point frames that notches out the one or two strongest steady lines; on = 0 / 1
+ * re-initialises its state.  qk_set_rit_freq: the CW sidetone offset that a CW receiver's notch leaves alone (set_sidetone's
+ * rit_freq, quisk.c:4335-4343).  qk_is_squelch = IsSquelch (quisk.c:1231-1252; get_squelch, quisk.c:2645-2652): 1 when the mean
+ * of the last released graph row over 5 kHz around freq is below the squelch level or off screen. */
+int qk_set_ssb_squelch(qk_engine *e, int enabled, int level);
+int qk_set_auto_notch(qk_engine *e, int rx, int on);
+int qk_set_rit_freq(qk_engine *e, int hz);
+int qk_is_squelch(qk_engine *e, int freq);
 /* Second-receiver routing (quisk.c:2410-2494): the output of receiver rx becomes stereo, made of its own audio and the
  * audio of partner_rx, both behind their own AGCs (the reference's Agc1 / Agc2, quisk.c:2563-2572), with the counts of the two
  * equalised by Buffer2Chan's FIFOs (quisk.c:1452-1487; BUF2CHAN_SIZE scaled to the play rate).

@@ -462,10 +462,166 @@ struct qko_rx {
     int idx_c; double *ring_i, *ring_q;
     int idx_d; qko_cd *ring_c;
     qko_fracstate frac;
+    /* SSB squelch (quisk.c:1022-1116; ssb_squelch_enabled / _level 148-149) with its delay line d_delay (993-1020) */
+    int ssb_sq_enabled, ssb_sq_level, ssb_plan, ssb_index, ssb_open; double ssb_in[512], ssb_delay[512]; int ssb_didx, ssb_dalloc;
+    /* auto-notch (dAutoNotch, quisk.c:730-899): its function statics */
+    int notch_on, rit_freq; struct qko_notch *notch;
     qko_chb45 play_hb[3];                                /* HalfBand7..9, quisk.c:2178-2180 */
     qko_agc agc;                                         /* Agc1, quisk.c:2181 */
     double *audio; int naudio;
 };
+
+#define NOTCH_N 2048                 /* NOTCH_DATA_SIZE and the sizes derived from it, quisk.c:723-729 */
+#define NOTCH_DESIGN (NOTCH_N / 4)
+#define NOTCH_TAPS (NOTCH_DESIGN - 1)
+#define NOTCH_FBINS (NOTCH_TAPS / 2 + 1)
+#define NOTCH_START (NOTCH_TAPS - 1)
+#define NOTCH_OUT (NOTCH_N - NOTCH_START)
+#define NOTCH_BINS (NOTCH_N / 2 + 1)
+struct qko_notch {
+    int old1, count1, old2, count2, index, sig;
+    double data_in[NOTCH_N], data_out[NOTCH_N], window[NOTCH_N], average[NOTCH_BINS], fltr_out[NOTCH_DESIGN];
+    qko_cd fltr_fft[NOTCH_BINS];
+};
+static void notch_reset(struct qko_notch *s)
+{   /* dAutoNotch(NULL, ...), quisk.c:761-770; the window is made with the plans (757-759) */
+    int i;
+    memset(s, 0, sizeof *s);
+    s->index = NOTCH_START; s->sig = -1; s->count1 = s->count2 = -4;
+    for (i = 0; i < NOTCH_TAPS; i++) s->window[i] = 0.50 - 0.50 * cos(2. * M_PI * i / (NOTCH_TAPS));
+}
+/* FFTW's r2c / c2r transforms through the complex DFT: r2c keeps bins 0 .. n/2; c2r (unnormalised) takes bins 0 .. n/2 of a
+ * Hermitian spectrum and ignores the imaginary parts of bins 0 and n/2 */
+static void r2c(const double *in, qko_cd *out, int n, qko_cd *work)
+{
+    int i;
+    for (i = 0; i < n; i++) work[i] = in[i];
+    qko_fft(work, n);
+    for (i = 0; i <= n / 2; i++) out[i] = work[i];
+}
+static void c2r(const qko_cd *in, double *out, int n, qko_cd *work)
+{
+    int i;
+    work[0] = creal(in[0]); work[n / 2] = creal(in[n / 2]);
+    for (i = 1; i < n / 2; i++) { work[i] = conj(in[i]); work[n - i] = in[i]; }     /* inverse = conj(FFT(conj X)); the result is real */
+    qko_fft(work, n);
+    for (i = 0; i < n; i++) out[i] = creal(work[i]);
+}
+static void auto_notch(struct qko_notch *s, double *dsamples, int nSamples, int sidetone, int rate)
+{   /* dAutoNotch, quisk.c:775-897 */
+    int i, j, k, i1, i2, inp, signal, delta_sig, delta_i1, half_width;
+    double d, d1, d2;
+    static qko_cd work[NOTCH_N], spec[NOTCH_BINS], fdesign[NOTCH_BINS];
+    static double fltr_in[NOTCH_N];
+    for (inp = 0; inp < nSamples; inp++) {
+        s->data_in[s->index] = dsamples[inp];
+        dsamples[inp] = s->data_out[s->index];
+        if (++s->index >= NOTCH_N) {
+            s->index = NOTCH_START;
+            r2c(s->data_in, spec, NOTCH_N, work);
+            delta_sig = (300 * 2 * NOTCH_BINS + rate / 2) / rate;
+            delta_i1 = (400 * 2 * NOTCH_BINS + rate / 2) / rate;
+            signal = sidetone != 0 ? (abs(sidetone) * 2 * NOTCH_BINS + rate / 2) / rate : -999;
+            d1 = 0; i1 = 0;
+            for (i = 0; i < NOTCH_BINS; i++) {
+                d = cabs(spec[i]);
+                s->average[i] = 0.5 * s->average[i] + 0.5 * d;
+                if (abs(i - signal) > delta_sig && s->average[i] > d1) { d1 = s->average[i]; i1 = i; }
+            }
+            if (abs(i1 - s->old1) < 3) s->count1++; else s->count1--;
+            if (s->count1 > 4) s->count1 = 4; else if (s->count1 < -1) s->count1 = -1;
+            if (s->count1 < 0) s->old1 = i1;
+            d2 = 0; i2 = 0;
+            for (i = 0; i < NOTCH_BINS; i++)
+                if (abs(i - signal) > delta_sig && abs(i - i1) > delta_i1 && s->average[i] > d2) { d2 = s->average[i]; i2 = i; }
+            if (abs(i2 - s->old2) < 3) s->count2++; else s->count2--;
+            if (s->count2 > 4) s->count2 = 4; else if (s->count2 < -2) s->count2 = -2;
+            if (s->count2 < 0) s->old2 = i2;
+            if (s->count1 > 0 && s->count2 > 0) k = i1 + 10000 * i2;
+            else if (s->count1 > 0) k = i1;
+            else k = 0;
+            if (s->sig != k) {                           /* make the filter: quisk.c:844-886 */
+                s->sig = k;
+                half_width = (100 * 2 * NOTCH_FBINS + rate / 2) / rate;
+                if (half_width < 3) half_width = 3;
+                /* the design array IS fltr_fft (quisk.c:849-850): bins 0 .. 255 are set; bin 256, the Nyquist bin of the
+                   512-point inverse transform, keeps what the last 2048-point filter spectrum left there (0 at first) */
+                for (i = 0; i < NOTCH_BINS; i++) fdesign[i] = s->fltr_fft[i];
+                for (i = 0; i < NOTCH_FBINS; i++) fdesign[i] = 1.0;
+                k = (i1 + 2) / 4;
+                if (s->count1 > 0)
+                    for (i = -half_width; i <= half_width; i++) { j = k + i; if (j >= 0 && j < NOTCH_FBINS) fdesign[j] = 0.0; }
+                k = (i2 + 2) / 4;
+                if (s->count1 > 0 && s->count2 > 0)
+                    for (i = -half_width; i <= half_width; i++) { j = k + i; if (j >= 0 && j < NOTCH_FBINS) fdesign[j] = 0.0; }
+                c2r(fdesign, s->fltr_out, NOTCH_DESIGN, work);         /* bins 0 .. NOTCH_DESIGN / 2 = NOTCH_FBINS - 1 + ... */
+                memmove(s->fltr_out + NOTCH_DESIGN / 2 - 1, s->fltr_out, sizeof(double) * (NOTCH_TAPS / 2 - 1));
+                for (i = NOTCH_DESIGN / 2 - 2, j = NOTCH_DESIGN / 2; i >= 0; i--, j++) s->fltr_out[i] = s->fltr_out[j];
+                for (i = 0; i < NOTCH_TAPS; i++) fltr_in[i] = s->fltr_out[i] * s->window[i] / NOTCH_DESIGN;
+                for (i = NOTCH_TAPS; i < NOTCH_N; i++) fltr_in[i] = 0.0;
+                r2c(fltr_in, s->fltr_fft, NOTCH_N, work);
+            }
+            for (i = 0; i < NOTCH_BINS; i++) spec[i] *= s->fltr_fft[i];
+            c2r(spec, s->data_out, NOTCH_N, work);
+            memmove(s->data_in, s->data_in + NOTCH_OUT, NOTCH_START * sizeof(double));
+            for (i = NOTCH_START; i < NOTCH_N; i++) s->data_out[i] /= NOTCH_N / 20;
+        }
+    }
+}
+
+static void ssb_squelch(qko_rx *rx, double *dsamples, int nSamples, int samp_rate)
+{   /* quisk.c:1022-1116; the caller's first call only builds the plan */
+    int i, bw, bw1, bw2, inp;
+    double d, arith_avg, geom_avg, ratio;
+    static qko_cd work[512], out[257];
+    double win[512];
+    if (!rx->ssb_plan) { rx->ssb_plan = 1; rx->ssb_index = 0; rx->ssb_open = 0; return; }
+    for (inp = 0; inp < nSamples; inp++) {
+        rx->ssb_in[rx->ssb_index++] = dsamples[inp];
+        if (rx->ssb_index >= 512) {
+            rx->ssb_index = 0;
+            for (i = 0; i < 512; i++) win[i] = rx->ssb_in[i] * (0.50 - 0.50 * cos(2. * M_PI * i / 512));
+            r2c(win, out, 512, work);
+            bw = rx->bandwidth; if (bw > 3000) bw = 3000;
+            bw1 = 300 * 512 / samp_rate;
+            bw2 = (bw + 300) * 512 / samp_rate;
+            arith_avg = 0.0; geom_avg = 0.0;
+            for (i = bw1; i < bw2; i++) {
+                qko_cd c = out[i] / 32767;
+                d = creal(c) * creal(c) + cimag(c) * cimag(c);
+                if (d > 1E-4) { arith_avg += d; geom_avg += log(d); }
+            }
+            if (arith_avg > 1E-4) { bw = bw2 - bw1; arith_avg = log(arith_avg / bw); geom_avg /= bw; ratio = arith_avg - geom_avg; }
+            else ratio = 1.0;
+            if (ratio > rx->ssb_sq_level * 0.005) rx->ssb_open = samp_rate;
+        }
+    }
+    rx->ssb_open -= nSamples;
+    if (rx->ssb_open < 0) rx->ssb_open = 0;
+    rx->sq_active = rx->ssb_open == 0;
+}
+static void ssb_delay(qko_rx *rx, double *dsamples, int nSamples)
+{   /* d_delay by SQUELCH_FFT_SIZE samples, quisk.c:993-1020 */
+    int i;
+    for (i = 0; i < nSamples; i++) {
+        double v = rx->ssb_delay[rx->ssb_didx];
+        rx->ssb_delay[rx->ssb_didx] = dsamples[i];
+        dsamples[i] = v;
+        if (++rx->ssb_didx >= 512) rx->ssb_didx = 0;
+    }
+}
+static void audio_hooks(qko_rx *rx, double *a, int n, int sidetone, int squelch)
+{   /* the calls between the detector and the audio interpolators, quisk.c:1792-1793, 1829-1834, 1879-1884 */
+    if (rx->notch_on && rx->notch) auto_notch(rx->notch, a, n, sidetone, rx->filter_srate);
+    if (squelch && rx->ssb_sq_enabled) { ssb_squelch(rx, a, n, rx->filter_srate); ssb_delay(rx, a, n); }
+}
+void qko_rx_set_ssb_squelch(qko_rx *rx, int enabled, int level) { rx->ssb_sq_enabled = enabled; rx->ssb_sq_level = level; }   /* quisk.c:4356-4362 */
+void qko_rx_set_auto_notch(qko_rx *rx, int on, int rit_freq)
+{   /* set_auto_notch, quisk.c:4237-4244: also re-initialises */
+    if (!rx->notch) rx->notch = (struct qko_notch *)malloc(sizeof(struct qko_notch));
+    notch_reset(rx->notch);
+    rx->notch_on = on; rx->rit_freq = rit_freq;
+}
 
 qko_rx *qko_rx_new(int sample_rate, int playback_rate)
 {
@@ -521,7 +677,7 @@ void qko_rx_free(qko_rx *rx)
     for (i = 0; i < 3; i++) free(rx->play_hb[i].scratch);
     free(rx->fi); free(rx->fq); free(rx->ring_i); free(rx->ring_q); free(rx->ring_c);
     qko_agc_free(&rx->agc);
-    free(rx->audio);
+    free(rx->audio); free(rx->notch);
     free(rx);
 }
 
@@ -670,6 +826,7 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
             c = rx_bandpass_iq(rx, x[i]);
             a[i] = rx->mode == QKO_CWL ? creal(c) + cimag(c) : creal(c) - cimag(c);
         }
+        audio_hooks(rx, a, n, rx->rit_freq, 0);
         n = qko_dinterpolate(a, n, &rx->aud12p2, 2);
         n = qko_dinterp2hb45(a, n, &rx->dem_hb6);
         n = qko_dinterp2hb45(a, n, &rx->dem_hb7);
@@ -685,6 +842,7 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
             rx->dc_remove = d;
         }
         n = qko_dfilter(a, n, &rx->aud24p6);
+        audio_hooks(rx, a, n, 0, 1);
         n = qko_dinterp2hb45(a, n, &rx->dem_hb7);
         break;
     case QKO_FM: case QKO_DGT_FM:
@@ -702,6 +860,7 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
         n = qko_ddecimate(a, n, &rx->aud24p3, 2);
         n = qko_dfilter(a, n, &rx->fmhp);
         n = qko_dinterp2hb45(a, n, &rx->dem_hb6);
+        audio_hooks(rx, a, n, 0, 0);                     /* quisk.c:1909-1910 */
         if (rx->sq_rf_count >= 2400) {                   /* quisk.c:1911-1918: mean magnitude in dB re full scale */
             rx->sq_value = rx->sq_rf_sum / rx->sq_rf_count / QKO_CLIP32;
             rx->sq_value = rx->sq_value > 1.E-10 ? 20 * log10(rx->sq_value) : -200.0;
@@ -723,6 +882,7 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
             c = rx_bandpass_iq(rx, x[i]);
             a[i] = rx->mode == QKO_DGT_L ? creal(c) + cimag(c) : creal(c) - cimag(c);
         }
+        audio_hooks(rx, a, n, 0, 0);                     /* quisk.c:1940-1941, 1966-1967 */
         if (narrow) {
             n = qko_dinterpolate(a, n, &rx->aud12p2, 2);
             n = qko_dinterp2hb45(a, n, &rx->dem_hb6);
@@ -742,6 +902,7 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
             c = rx_bandpass_iq(rx, x[i]);
             a[i] = rx->mode == QKO_LSB ? creal(c) + cimag(c) : creal(c) - cimag(c);
         }
+        audio_hooks(rx, a, n, 0, 1);
         n = qko_dinterpolate(a, n, &rx->aud24p4, 2);
         n = qko_dinterp2hb45(a, n, &rx->dem_hb7);
         break;

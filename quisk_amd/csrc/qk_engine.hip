@@ -59,6 +59,9 @@ struct Stage {
     double a0 = 0, a1 = 0, b1 = 0, fs = 0;
     double *iir_state = nullptr;
     int timer = -1;            // QK_KT_* bucket
+    int hook = 0;              // audio hooks behind this stage: 1 = auto-notch and SSB squelch, 2 = auto-notch only (quisk.c:1792, 1829-1834, 1909)
+    int hook_div = 1;          // the hooks' sample rate is decim_srate / hook_div (quisk_filter_srate; 48 k behind the FM chain)
+    bool delayed = false;      // this stage reads its input SSQ_N samples late while the SSB squelch is on (d_delay, quisk.c:1833)
 };
 
 struct Chain {
@@ -163,6 +166,10 @@ struct qk_engine {
     // output
     double2 *d_out = nullptr; size_t out_stride = 0;
     std::vector<int> out_count;
+    // SSB squelch (quisk.c:1022-1116) and auto-notch (quisk.c:730-899)
+    int ssb_sq_enabled = 0, ssb_sq_level = 0, rit_freq = 0;
+    double *d_ssb_carry = nullptr; int *d_ssb_state = nullptr, *d_bw = nullptr, *d_notch_on = nullptr;
+    NotchState *d_notch = nullptr; std::vector<int> notch_on; bool any_notch = false;
     // second-receiver routing (quisk.c:2410-2494) and Buffer2Chan's FIFOs (quisk.c:1452-1487), one per routed receiver
     struct Route { int rx = 0, partner = 0, method = 0, nbuf_a = 0, nbuf_b = 0, cur = 0; double *fifo[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; };
     std::vector<Route> routes; double2 *d_route_tmp = nullptr; int route_cap = 0;
@@ -174,6 +181,7 @@ struct qk_engine {
     int fft_batch = FFT_BATCH;             // frames per launch pair (QK_FFT_BATCH, 1..FFT_BATCH)
     int fft_parts = 0;                     // partial averages of the four-step row pass that hold data (0 after a release)
     double *h_graph = nullptr;             // pinned staging of a released row + the S-meter sum
+    long long graph_rows = 0;              // rows released so far (current_graph is all zero before the first)
     double k0_zoom = 0, k0_deltaf = 0; bool k0_valid = false;     // what d_k0 was made for
     double2 *d_fft_stage = nullptr, *d_fft_Y = nullptr, *d_tw4096 = nullptr, *d_tw_lo = nullptr, *d_tw_hi = nullptr;
     double *d_window = nullptr, *d_fft_avg = nullptr, *d_band = nullptr, *d_meter = nullptr, *d_graph = nullptr, *d_pix = nullptr;
@@ -441,7 +449,10 @@ static int build_class(qk_engine *e, int cl)
         b.fir(e->f_hbdec, 2, T_A);
         b.fir(e->f_dec2, 2, T_A);
         rxf(0, 1);
+        c.stages.back().hook = 1; c.stages.back().hook_div = 4;
+        b.need_hist(b.cur, SSQ_N + 50 / 2);
         b.interp(e->h_a24p4, 50, 2, T_B);
+        c.stages.back().delayed = true;
         b.hbint(1, T_B);
         break;
     case CL_CW:     // quisk.c:1779-1816
@@ -449,6 +460,7 @@ static int build_class(qk_engine *e, int cl)
         b.fir(e->f_hbdec, 2, T_A);
         b.fir(e->f_dec2, 2, T_A);
         rxf(0, 1);
+        c.stages.back().hook = 2; c.stages.back().hook_div = 8;
         b.interp(e->h_a24p4, 50, 2, T_B);
         b.hbint(1, T_B);
         b.hbint(1, T_B);
@@ -458,10 +470,14 @@ static int build_class(qk_engine *e, int cl)
         rxf(1, 1);
         rc = iir(0);
         b.fir(e->f_a24p6, 1, T_B);
+        c.stages.back().hook = 1; c.stages.back().hook_div = 2;
+        b.need_hist(b.cur, SSQ_N + 24);
         b.hbint(1, T_B);
+        c.stages.back().delayed = true;
         break;
     case CL_DGTW:   // quisk.c:1929-1939, 1955-1965
         rxf(0, 1);
+        c.stages.back().hook = 2;
         break;
     case CL_DGTIQ:  // quisk.c:1974-1986: dRxFilterOut on the complex stream (none at 19 kHz and above), no detector
         rxf(2, 2);
@@ -475,6 +491,7 @@ static int build_class(qk_engine *e, int cl)
         b.fir(e->f_a24p3, 1, T_B);
         b.fir(e->f_fmhp, 1, T_B);
         b.hbint(1, T_B);
+        c.stages.back().hook = 2;
         break;
     }
     }
@@ -690,6 +707,15 @@ static int init_receivers(qk_engine *e)
     e->gain_stride = (int)e->out_stride;
     HIPCHECK(hipMalloc(&e->d_out, nrx * e->out_stride * sizeof(double2)));
     HIPCHECK(hipMemset(e->d_out, 0, nrx * e->out_stride * sizeof(double2)));
+    HIPCHECK(hipMalloc(&e->d_ssb_carry, nrx * SSQ_N * sizeof(double)));
+    HIPCHECK(hipMemset(e->d_ssb_carry, 0, nrx * SSQ_N * sizeof(double)));
+    HIPCHECK(hipMalloc(&e->d_ssb_state, nrx * 4 * sizeof(int)));
+    HIPCHECK(hipMemset(e->d_ssb_state, 0, nrx * 4 * sizeof(int)));
+    HIPCHECK(hipMalloc(&e->d_bw, nrx * sizeof(int)));
+    HIPCHECK(hipMemset(e->d_bw, 0, nrx * sizeof(int)));
+    HIPCHECK(hipMalloc(&e->d_notch_on, nrx * sizeof(int)));
+    HIPCHECK(hipMemset(e->d_notch_on, 0, nrx * sizeof(int)));
+    e->notch_on.assign(nrx, 0);
     e->route_cap = 12000 * (cfg.playback_rate / 48000);                  // BUF2CHAN_SIZE (quisk.c:1452) at the play rate
     e->keyup_cap = (int)(cfg.playback_rate * 5e-3) + 8;
     HIPCHECK(hipHostMalloc(&e->h_keyup, sizeof(double) * e->keyup_cap, hipHostMallocMapped));
@@ -1204,6 +1230,7 @@ static int release_graph(qk_engine *e, double zoom, double deltaf, double *out, 
     memcpy(out, e->h_graph, sizeof(double) * W);
     const double meter = e->h_graph[W];
     e->fft_parts = 0;
+    e->graph_rows++;
     const double scale = 1.0 / 2147483647.0 / N;                    // quisk.c:4728-4737
     double sm = meter * scale * scale / count;
     sm = sm > 0 ? 10.0 * log10(sm) : -160.0;
@@ -1246,7 +1273,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         case ST_INTERP: {
             out.n = n_in * st.L;
             if (out.n > 0) {
-                InterpArgs a{in.view(), out.view(), st.h, st.T, st.L, n_in, d_list};
+                InterpArgs a{in.view(), out.view(), st.h, st.T, st.L, n_in, d_list, (st.delayed && e->ssb_sq_enabled) ? SSQ_N : 0};
                 Timer tm(e, st.timer);
                 hipLaunchKernelGGL(k_interp, grid1(out.n, 1, nlist), dim3(256), 0, e->stream, a);
             }
@@ -1255,7 +1282,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         case ST_HBINT: {
             out.n = n_in * 2;
             if (n_in > 0) {
-                HbInterpArgs a{in.view(), out.view(), n_in, d_list};
+                HbInterpArgs a{in.view(), out.view(), n_in, d_list, (st.delayed && e->ssb_sq_enabled) ? SSQ_N : 0};
                 Timer tm(e, st.timer);
                 hipLaunchKernelGGL(k_hb_interp, grid1(n_in, in.planes, nlist), dim3(256), 0, e->stream, a);
             }
@@ -1343,6 +1370,19 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             }
             break;
         }
+        }
+        if (st.hook && out.n > 0) {
+            const int rate = e->decim_srate / st.hook_div;
+            const bool cw = &c == &e->cls_chain[CL_CW];
+            if (e->any_notch) {
+                NotchArgs na{out.view(), out.n, rate, cw ? e->rit_freq : 0, d_list, e->d_notch_on, e->d_mode, e->d_notch, e->d_tw4096};
+                hipLaunchKernelGGL(k_auto_notch, dim3(nlist), dim3(256), 0, e->stream, na);
+            }
+            if (st.hook == 1 && e->ssb_sq_enabled) {
+                SsbSquelchArgs sa{out.view(), out.n, rate, e->ssb_sq_level, d_list, e->d_bw, e->d_ssb_carry, e->d_ssb_state,
+                                  e->d_sq_flag + (e->pipe_blocks & 1) * e->nrx, e->d_tw4096};
+                hipLaunchKernelGGL(k_ssb_squelch, dim3(nlist), dim3(256), 0, e->stream, sa);
+            }
         }
     }
     return QK_OK;
@@ -1747,6 +1787,7 @@ void qk_destroy(qk_engine *e)
     if (e->h_keyup_counts) hipHostFree(e->h_keyup_counts);
     if (e->ev_keyup) hipEventDestroy(e->ev_keyup);
     if (e->d_route_tmp) hipFree(e->d_route_tmp);
+    for (void *p : {(void *)e->d_ssb_carry, (void *)e->d_ssb_state, (void *)e->d_bw, (void *)e->d_notch_on, (void *)e->d_notch}) if (p) hipFree(p);
     for (auto &r : e->routes) for (auto &q : r.fifo) for (double *p : q) if (p) hipFree(p);
     for (void *p : {(void *)e->d_scan_avg, (void *)e->d_raw_rows, (void *)e->d_rfb_x[0], (void *)e->d_rfb_x[1], (void *)e->d_rfb_x[2], (void *)e->d_rfb_y, (void *)e->d_rfb_t}) if (p) hipFree(p);
     for (auto &ev : e->ev_pool) if (ev) hipEventDestroy(ev);
@@ -1836,6 +1877,7 @@ int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int
         }
     }
     e->ntaps[rx] = n; e->bandwidth[rx] = bandwidth; e->start_offset[rx] = start_offset;
+    HIPCHECK(hipMemcpy(e->d_bw + rx, &bandwidth, sizeof(int), hipMemcpyHostToDevice));
     { int rcn = upload_ntaps(e, rx); if (rcn != QK_OK) return rcn; }
     const int cl = class_of_mode(e->mode[rx], bandwidth);      // DGT-U/L change chain with the bandwidth
     if (cl >= 0 && cl != e->cls[rx]) {
@@ -2169,6 +2211,67 @@ int qk_get_bandscope(qk_engine *e, int clock, double zoom, double deltaf, double
     if (adc_level) { double d; memcpy(&d, &mx, sizeof d); *adc_level = d; }     // hermes_adc_level, quisk.c:4591
     e->bs_count = 0;
     return count;
+}
+
+int qk_set_ssb_squelch(qk_engine *e, int enabled, int level)
+{
+    ENGINE_ENTER(e);
+    SYNC_ALL(e);
+    if (e->nrx > 0 && !enabled && e->ssb_sq_enabled) {      // receivers the SSB squelch had closed open again
+        std::vector<int> fl(2 * (size_t)e->nrx);
+        HIPCHECK(hipMemcpy(fl.data(), e->d_sq_flag, fl.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int b = 0; b < 2; b++) for (int r = 0; r < e->nrx; r++) if (e->cls[r] != CL_FM) fl[(size_t)b * e->nrx + r] = 0;
+        HIPCHECK(hipMemcpy(e->d_sq_flag, fl.data(), fl.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    e->ssb_sq_enabled = enabled != 0; e->ssb_sq_level = level;
+    return QK_OK;
+}
+
+static int notch_reset(qk_engine *e, int rx)
+{   // dAutoNotch(NULL, ...), quisk.c:761-770
+    if (!e->d_notch) return QK_OK;
+    HIPCHECK(hipMemset(e->d_notch + rx, 0, sizeof(NotchState)));
+    const int init[8] = {AN_START, 0, -4, 0, -4, -1, 0, 0};     // index, old1, count1, old2, count2, fltrSig
+    HIPCHECK(hipMemcpy(e->d_notch + rx, init, sizeof init, hipMemcpyHostToDevice));
+    return QK_OK;
+}
+
+int qk_set_auto_notch(qk_engine *e, int rx, int on)
+{
+    ENGINE_ENTER(e); RX_CHECK(e, rx);
+    SYNC_ALL(e);
+    if (on && !e->d_notch) HIPCHECK(hipMalloc(&e->d_notch, sizeof(NotchState) * (size_t)e->nrx));
+    on = on != 0;
+    e->notch_on[rx] = on;
+    HIPCHECK(hipMemcpy(e->d_notch_on + rx, &on, sizeof(int), hipMemcpyHostToDevice));
+    e->any_notch = false;
+    for (int v : e->notch_on) e->any_notch = e->any_notch || v;
+    return notch_reset(e, rx);
+}
+
+int qk_set_rit_freq(qk_engine *e, int hz)
+{
+    ENGINE_ENTER(e);
+    SYNC_ALL(e);
+    e->rit_freq = hz;
+    for (int r = 0; r < e->nrx; r++)                        // for CW, changing the RIT affects the notch (quisk.c:4343)
+        if (e->notch_on[r]) { int rc = notch_reset(e, r); if (rc != QK_OK) return rc; }
+    return QK_OK;
+}
+
+int qk_is_squelch(qk_engine *e, int freq)
+{   // IsSquelch, quisk.c:1231-1252, on the graph row of the last release (current_graph, quisk.c:4747)
+    ENGINE_ENTER(e);
+    if (e->fftN <= 0 || !e->h_graph) return fail(QK_EINVAL, "engine created without a display FFT");
+    const int W = e->fftW, fs = e->cfg.sample_rate;
+    int bw = 5000 * W / fs;
+    if (bw < 1) bw = 1;
+    const int i1 = (int)((double)freq * W / fs + W / 2.0 - bw / 2.0 + 0.5), i2 = i1 + bw;
+    double meter = 0;
+    if (i1 >= 0 && i2 < W && e->graph_rows > 0)
+        for (int i = i1; i < i2; i++) meter += e->h_graph[i];
+    meter /= bw;
+    return (meter == 0 || meter < e->squelch_level) ? 1 : 0;
 }
 
 int qk_set_stereo_route(qk_engine *e, int rx, int partner_rx, int method)

@@ -670,3 +670,237 @@ __global__ __launch_bounds__(256) void k_bscope_release(BscopeRelease a)
     sample = sample * a.scale;
     a.out[i] = sample <= 1E-10 ? -200.0 : 20.0 * log10(sample);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Audio-rate hooks between the detector and the audio interpolators (quisk.c:1792-1793, 1829-1834, 1879-1884, 1909-1910,
+// 1940-1941): the SSB squelch and the automatic notch filter.  Both work on frames of the receiver's audio that are
+// transformed one after the other with state carried from frame to frame (a hysteresis, a one-second timer): one
+// workgroup per receiver walks the frames of a block in order; the transforms inside a frame are the LDS FFT above.
+// ------------------------------------------------------------------------------------------------
+#define SSQ_N 512                  /* SQUELCH_FFT_SIZE, quisk.c:36 */
+struct SsbSquelchArgs {
+    StreamView au;                 // the audio stream at the filter rate (one plane)
+    int n, samp_rate, level;       // new samples of this block; quisk_filter_srate; ssb_squelch_level
+    const int *rx_list; const int *bandwidth;     // [rx] filter bandwidth (the reference reads bank 0's, quisk.c:1056)
+    double *carry;                 // [rx][SSQ_N] samples of the unfinished frame (MS->in_fft)
+    int *state;                    // [rx][4]: index, sq_open, plan made, -
+    int *flag;                     // [rx] squelch_active of this block
+    const double2 *tw4096;
+};
+__device__ __forceinline__ double block_sum(double v, double *red)
+{
+    __syncthreads();
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    return red[0];
+}
+__global__ __launch_bounds__(256) void k_ssb_squelch(SsbSquelchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double2 buf[SSQ_N];
+    __shared__ double red[256];
+    const int rx = a.rx_list ? a.rx_list[blockIdx.x] : blockIdx.x;
+    int *st = a.state + 4 * rx;
+    if (!st[2]) {                  // the first call only makes the plan (quisk.c:1040-1048): the block is not analysed and the
+        __syncthreads();           // flag keeps the 0 that quisk.c:1777 gave it
+        if (threadIdx.x == 0) { st[0] = 0; st[1] = 0; st[2] = 1; a.flag[rx] = 0; }
+        return;
+    }
+    const int idx0 = st[0];
+    const double *x = sv_ptr(a.au, rx, 0);
+    double *carry = a.carry + (long long)rx * SSQ_N;
+    const int frames = (idx0 + a.n) / SSQ_N;
+    int bw = a.bandwidth[rx];
+    if (bw > 3000) bw = 3000;
+    const int bw1 = 300 * SSQ_N / a.samp_rate, bw2 = (bw + 300) * SSQ_N / a.samp_rate;
+    bool opened = false;
+    for (int f = 0; f < frames; f++) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < SSQ_N; j += 256) {
+            const int pos = f * SSQ_N + j;
+            const double v = pos < idx0 ? carry[pos] : x[pos - idx0];
+            buf[j] = make_double2(v * (0.50 - 0.50 * cos(2. * M_PI * j / SSQ_N)), 0.0);
+        }
+        lds_fft<SSQ_N>(buf, SSQ_N, 1, a.tw4096);
+        double ar = 0.0, ge = 0.0;
+        for (int i = bw1 + (int)threadIdx.x; i < bw2; i += 256) {
+            const double re = buf[i].x / 32767, im = buf[i].y / 32767;          // CLIP16, quisk.c:1064
+            const double d = re * re + im * im;
+            if (d > 1E-4) { ar += d; ge += log(d); }
+        }
+        ar = block_sum(ar, red);
+        ge = block_sum(ge, red);
+        double ratio = 1.0;
+        if (ar > 1E-4) { const int nb = bw2 - bw1; ratio = log(ar / nb) - ge / nb; }
+        if (ratio > a.level * 0.005) opened = true;                            // MS->sq_open = samp_rate: a one second timer
+    }
+    __syncthreads();
+    // what is left of (carry + block) behind the last whole frame becomes the new carry
+    const int rest = idx0 + a.n - frames * SSQ_N;
+    double keep[2];
+    for (int u = 0; u < 2; u++) {
+        const int j = threadIdx.x + 256 * u;
+        const int pos = frames * SSQ_N + j;
+        keep[u] = (j < rest) ? (pos < idx0 ? carry[pos] : x[pos - idx0]) : 0.0;
+    }
+    __syncthreads();
+    for (int u = 0; u < 2; u++) { const int j = threadIdx.x + 256 * u; if (j < rest) carry[j] = keep[u]; }
+    if (threadIdx.x == 0) {
+        int open = opened ? a.samp_rate : st[1];
+        open -= a.n;
+        if (open < 0) open = 0;
+        st[0] = rest; st[1] = open;
+        a.flag[rx] = open == 0;
+    }
+}
+
+#define AN_N 2048                  /* NOTCH_DATA_SIZE and the sizes quisk.c:723-729 derive from it */
+#define AN_DESIGN (AN_N / 4)
+#define AN_TAPS (AN_DESIGN - 1)
+#define AN_FBINS (AN_TAPS / 2 + 1)
+#define AN_START (AN_TAPS - 1)
+#define AN_OUT (AN_N - AN_START)
+#define AN_BINS (AN_N / 2 + 1)
+struct NotchState {                // dAutoNotch's function statics (quisk.c:734-746), per receiver
+    int index, old1, count1, old2, count2, sig, pad0, pad1;
+    double data_in[AN_N], data_out[AN_N], average[AN_BINS + 7];
+    double2 fltr_fft[AN_BINS + 1];
+};
+struct NotchArgs {
+    StreamView au; int n, rate, sidetone;
+    const int *rx_list; const int *on;      // [rx] auto-notch enabled
+    const int *mode;                        // [rx] rx_mode_type: only CWL / CWU pass a sidetone (quisk.c:1793, 1812; 0 elsewhere)
+    NotchState *state;                      // [rx]
+    const double2 *tw4096;
+};
+// largest value of v over the workgroup with the lowest index among equals; entries with v <= 0 never win (the reference starts
+// its search at d1 = 0, i1 = 0 with a strict comparison)
+__device__ __forceinline__ int block_argmax(double v, int i, double *redv, int *redi)
+{
+    __syncthreads();
+    redv[threadIdx.x] = v; redi[threadIdx.x] = i;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double w = redv[threadIdx.x + o]; const int wi = redi[threadIdx.x + o];
+            if (w > redv[threadIdx.x] || (w == redv[threadIdx.x] && wi < redi[threadIdx.x])) { redv[threadIdx.x] = w; redi[threadIdx.x] = wi; }
+        }
+        __syncthreads();
+    }
+    return redv[0] > 0.0 ? redi[0] : 0;
+}
+__global__ __launch_bounds__(256) void k_auto_notch(NotchArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double2 buf[AN_N];
+    __shared__ __attribute__((aligned(16))) double2 spec[AN_BINS + 1];
+    __shared__ double redv[256];
+    __shared__ int redi[256];
+    __shared__ int sh[4];
+    const int rx = a.rx_list ? a.rx_list[blockIdx.x] : blockIdx.x;
+    if (!a.on[rx]) return;
+    NotchState *s = a.state + rx;
+    double *x = sv_ptr(a.au, rx, 0);
+    const int t = threadIdx.x;
+    int index = s->index, inp = 0;
+    const int rate = a.rate;
+    const int delta_sig = (300 * 2 * AN_BINS + rate / 2) / rate, delta_i1 = (400 * 2 * AN_BINS + rate / 2) / rate;
+    const int sidetone = a.mode[rx] <= 1 ? a.sidetone : 0;
+    const int signal = sidetone != 0 ? (abs(sidetone) * 2 * AN_BINS + rate / 2) / rate : -999;
+    while (inp < a.n) {
+        const int chunk = min(a.n - inp, AN_N - index);
+        for (int j = t; j < chunk; j += 256) {           // quisk.c:776-777: the sample goes in, the filtered one of a frame ago comes out
+            const double v = x[inp + j];
+            s->data_in[index + j] = v;
+            x[inp + j] = s->data_out[index + j];
+        }
+        index += chunk; inp += chunk;
+        __syncthreads();
+        if (index < AN_N) break;
+        index = AN_START;
+        // ---- a full frame: forward transform (quisk.c:780) ----
+        for (int i = t; i < AN_N; i += 256) buf[i] = make_double2(s->data_in[i], 0.0);
+        lds_fft<AN_N>(buf, AN_N, 1, a.tw4096);
+        for (int i = t; i < AN_BINS; i += 256) spec[i] = buf[i];
+        // ---- the two strongest lines of the smoothed spectrum, away from the CW signal and from each other (quisk.c:792-835) ----
+        double bv = 0.0; int bi = 0;
+        for (int i = t; i < AN_BINS; i += 256) {
+            const double d = hypot(buf[i].x, buf[i].y);
+            const double av = 0.5 * s->average[i] + 0.5 * d;
+            s->average[i] = av;
+            if (abs(i - signal) > delta_sig && av > bv) { bv = av; bi = i; }
+        }
+        const int i1 = block_argmax(bv, bi, redv, redi);
+        bv = 0.0; bi = 0;
+        for (int i = t; i < AN_BINS; i += 256) {
+            const double av = s->average[i];
+            if (abs(i - signal) > delta_sig && abs(i - i1) > delta_i1 && av > bv) { bv = av; bi = i; }
+        }
+        const int i2 = block_argmax(bv, bi, redv, redi);
+        if (t == 0) {
+            int c1 = s->count1, c2 = s->count2;
+            if (abs(i1 - s->old1) < 3) c1++; else c1--;
+            if (c1 > 4) c1 = 4; else if (c1 < -1) c1 = -1;
+            if (c1 < 0) s->old1 = i1;
+            if (abs(i2 - s->old2) < 3) c2++; else c2--;
+            if (c2 > 4) c2 = 4; else if (c2 < -2) c2 = -2;
+            if (c2 < 0) s->old2 = i2;
+            s->count1 = c1; s->count2 = c2;
+            int k = 0;
+            if (c1 > 0 && c2 > 0) k = i1 + 10000 * i2; else if (c1 > 0) k = i1;
+            sh[0] = s->sig != k; sh[1] = c1 > 0; sh[2] = c1 > 0 && c2 > 0;
+            s->sig = k;
+        }
+        __syncthreads();
+        if (sh[0]) {               // ---- make the filter (quisk.c:844-886) ----
+            int half_width = (100 * 2 * AN_FBINS + rate / 2) / rate;
+            if (half_width < 3) half_width = 3;
+            const int k1 = (i1 + 2) / 4, k2 = (i2 + 2) / 4;
+            // the design spectrum: bins 0 .. 255 ones with the notches cut; bin 256 keeps the real part that the last
+            // 2048-point filter spectrum left in fltr_fft[256] (the reference designs in that array); Hermitian, real: its inverse
+            // real transform is the forward transform's real part
+            for (int k = t; k <= AN_DESIGN / 2; k += 256) {
+                double v = 1.0;
+                if (k == AN_DESIGN / 2) v = s->fltr_fft[AN_DESIGN / 2].x;
+                else if ((sh[1] && abs(k - k1) <= half_width) || (sh[2] && abs(k - k2) <= half_width)) v = 0.0;
+                buf[k] = make_double2(v, 0.0);
+                if (k > 0 && k < AN_DESIGN / 2) buf[AN_DESIGN - k] = make_double2(v, 0.0);
+            }
+            lds_fft<AN_DESIGN>(buf, AN_DESIGN, 1, a.tw4096);
+            // centre the response, mirror it, drop one tap (quisk.c:878-880, with what its overlapping copies really leave)
+            double tap[2];
+            for (int u = 0; u < 2; u++) {
+                const int i = t + 256 * u;
+                double v = 0.0;
+                if (i < AN_TAPS) {
+                    int src;
+                    if (i >= AN_DESIGN / 2 - 1) src = (i <= AN_DESIGN - 4) ? i - (AN_DESIGN / 2 - 1) : i;     // moved block / untouched tail
+                    else { const int j = AN_DESIGN - 2 - i; src = (j <= AN_DESIGN - 4) ? j - (AN_DESIGN / 2 - 1) : j; }
+                    v = buf[src].x * (0.50 - 0.50 * cos(2. * M_PI * i / (AN_TAPS))) / AN_DESIGN;
+                }
+                tap[u] = v;
+            }
+            __syncthreads();
+            for (int i = t; i < AN_N; i += 256) buf[i] = make_double2(0.0, 0.0);
+            __syncthreads();
+            for (int u = 0; u < 2; u++) { const int i = t + 256 * u; if (i < AN_TAPS) buf[i] = make_double2(tap[u], 0.0); }
+            lds_fft<AN_N>(buf, AN_N, 1, a.tw4096);
+            for (int i = t; i < AN_BINS; i += 256) s->fltr_fft[i] = buf[i];
+            __syncthreads();
+        }
+        // ---- apply the filter and transform back (quisk.c:890-892): conj(FFT(conj X)) of the Hermitian spectrum ----
+        for (int i = t; i < AN_BINS; i += 256) {
+            const double2 y = cmul_d(spec[i], s->fltr_fft[i]);
+            if (i == 0 || i == AN_N / 2) buf[i] = make_double2(y.x, 0.0);
+            else { buf[i] = make_double2(y.x, -y.y); buf[AN_N - i] = y; }
+        }
+        lds_fft<AN_N>(buf, AN_N, 1, a.tw4096);
+        // ---- slide the input, scale the output (quisk.c:893-895) ----
+        double keep[2];
+        for (int u = 0; u < 2; u++) { const int i = t + 256 * u; keep[u] = i < AN_START ? s->data_in[AN_OUT + i] : 0.0; }
+        __syncthreads();
+        for (int u = 0; u < 2; u++) { const int i = t + 256 * u; if (i < AN_START) s->data_in[i] = keep[u]; }
+        for (int i = AN_START + t; i < AN_N; i += 256) s->data_out[i] = buf[i].x / (AN_N / 20);
+        __syncthreads();
+    }
+    if (t == 0) s->index = index;
+}

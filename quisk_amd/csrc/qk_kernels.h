@@ -500,7 +500,7 @@ __global__ __launch_bounds__(NTH) void k_fir_tiled(FirTArgs a)
 
 // Polyphase interpolator x L (quisk_dInterpolate / quisk_cInterpolate, filter.c:108-178):
 // out[L i + jj] = L * sum_{k < T/L} h[jj + k L] x[i - k].
-struct InterpArgs { StreamView in, out; const double *h; int T, L, n_in; const int *rx_list; };
+struct InterpArgs { StreamView in, out; const double *h; int T, L, n_in; const int *rx_list; int delay; };   // delay: read the input this many samples back (d_delay behind the SSB squelch, quisk.c:1833)
 __global__ __launch_bounds__(256) void k_interp(InterpArgs a)
 {
     const int o = blockIdx.x * 256 + threadIdx.x;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_interp(InterpArgs a)
     const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
     const int plane = blockIdx.y;
     const int i = o / a.L, jj = o - i * a.L;
-    const double *__restrict__ p = sv_ptr(a.in, rx, plane) + i;
+    const double *__restrict__ p = sv_ptr(a.in, rx, plane) + i - a.delay;
     double acc = 0.0;
     const int terms = a.T / a.L;
     for (int k = 0; k < terms; k++) acc = fma(p[-k], a.h[jj + k * a.L], acc);
@@ -535,14 +535,14 @@ __global__ __launch_bounds__(256) void k_resample(ResampArgs a)
 
 // Half-band interpolator x 2 (quisk_dInterp2HB45 / quisk_cInterp2HB45, filter.c:397-465):
 // out[2i] = x[i-11] c[11] 2;  out[2i+1] = 2 sum_{k<11} (x[i-k] + x[i-21+k]) c[k].
-struct HbInterpArgs { StreamView in, out; int n_in; const int *rx_list; };
+struct HbInterpArgs { StreamView in, out; int n_in; const int *rx_list; int delay; };
 __global__ __launch_bounds__(256) void k_hb_interp(HbInterpArgs a)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n_in) return;
     const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
     const int plane = blockIdx.y;
-    const double *__restrict__ p = sv_ptr(a.in, rx, plane) + i;
+    const double *__restrict__ p = sv_ptr(a.in, rx, plane) + i - a.delay;
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < 11; k++) acc = fma(p[-k] + p[-21 + k], c_hb45[k], acc);

@@ -611,6 +611,39 @@ static PyObject *set_squelch(PyObject *self, PyObject *args)
     if (qk_set_squelch(G.qk, level) != QK_OK) return engine_error();
     Py_RETURN_NONE;
 }
+static PyObject *set_ssb_squelch(PyObject *self, PyObject *args)
+{   /* quisk.c:4356-4362 */
+    int enabled, level;
+    if (!PyArg_ParseTuple(args, "ii", &enabled, &level)) return NULL;
+    if (!need_engine()) return NULL;
+    if (qk_set_ssb_squelch(G.qk, enabled, level) != QK_OK) return engine_error();
+    Py_RETURN_NONE;
+}
+static PyObject *set_auto_notch(PyObject *self, PyObject *args)
+{   /* quisk.c:4237-4244: the reference's notch works on bank 0 */
+    int on;
+    if (!PyArg_ParseTuple(args, "i", &on)) return NULL;
+    if (!need_engine()) return NULL;
+    if (qk_set_auto_notch(G.qk, 0, on) != QK_OK) return engine_error();
+    Py_RETURN_NONE;
+}
+static PyObject *set_sidetone(PyObject *self, PyObject *args)
+{   /* quisk.c:4331-4346 ("idii"): of the four values the receive path uses rit_freq (the CW notch leaves it alone) */
+    int ctrl, rit, keyup;
+    double volume;
+    if (!PyArg_ParseTuple(args, "idii", &ctrl, &volume, &rit, &keyup)) return NULL;
+    if (G.qk && qk_set_rit_freq(G.qk, rit) != QK_OK) return engine_error();
+    Py_RETURN_NONE;
+}
+static PyObject *get_squelch(PyObject *self, PyObject *args)
+{   /* quisk.c:2645-2652 -> IsSquelch */
+    int freq;
+    if (!PyArg_ParseTuple(args, "i", &freq)) return NULL;
+    if (!need_engine()) return NULL;
+    const int v = qk_is_squelch(G.qk, freq);
+    if (v < 0) return engine_error();
+    return PyLong_FromLong(v);
+}
 static PyObject *rx_filter_block(PyObject *self, PyObject *args)
 {   /* cRxFilterOut over a block (an addition, like get_audio): (complex128 buffer, bank, nFilter) -> bytes */
     Py_buffer view;
@@ -660,6 +693,10 @@ static PyMethodDef QuiskMethods[] = {
     { "set_kill_audio", set_kill_audio, METH_VARARGS, "Replace radio sound with silence." },
     { "set_noise_blanker", set_noise_blanker, METH_VARARGS, "Set the noise blanker level." },
     { "set_squelch", set_squelch, METH_VARARGS, "Set the FM squelch parameter." },
+    { "set_ssb_squelch", set_ssb_squelch, METH_VARARGS, "Set the SSB squelch parameters." },
+    { "set_auto_notch", set_auto_notch, METH_VARARGS, "Set the auto notch on or off." },
+    { "set_sidetone", set_sidetone, METH_VARARGS, "Set the sidetone volume and frequency." },
+    { "get_squelch", get_squelch, METH_VARARGS, "Get the FM squelch state, 0 or 1." },
     { "set_split_rxtx", set_split_rxtx, METH_VARARGS, "Set split for rx/tx." },
     { "set_multirx_play_method", set_multirx_play_method, METH_VARARGS, "Select how to play audio from sub-receivers." },
     { "set_multirx_play_channel", set_multirx_play_channel, METH_VARARGS, "Select which sub-receiver to play audio." },
@@ -668,9 +705,9 @@ static PyMethodDef QuiskMethods[] = {
     { "is_key_down", (PyCFunction)inert_zero, METH_VARARGS | METH_KEYWORDS, "Receive only: the key is up." },
     { "get_hardware_ptt", (PyCFunction)inert_zero, METH_VARARGS | METH_KEYWORDS, "Receive only." },
     { "is_vox", (PyCFunction)inert_zero, METH_VARARGS | METH_KEYWORDS, "Receive only." },
-    INERT("set_volume"), INERT("set_ssb_squelch"), INERT("set_auto_notch"), INERT("set_enable_bandscope"), INERT("add_tone"), INERT("set_spot_level"), INERT("set_imd_level"),
+    INERT("set_volume"), INERT("set_enable_bandscope"), INERT("add_tone"), INERT("set_spot_level"), INERT("set_imd_level"),
     INERT("set_key_down"), INERT("set_PTT"), INERT("set_ctcss"), INERT("set_tx_audio"), INERT("set_record_state"), INERT("set_file_name"),
-    INERT("set_sidetone"), INERT("set_transmit_mode"), INERT("set_fdx"), INERT("set_sample_bytes"), INERT("change_rate"),
+    INERT("set_transmit_mode"), INERT("set_fdx"), INERT("set_sample_bytes"), INERT("change_rate"),
     INERT("change_rates"), INERT("change_scan"), INERT("open_sound"), INERT("open_key"), INERT("open_rx_udp"), INERT("close_rx_udp"),
     INERT("set_hermes_id"), INERT("set_hermes_filters"), INERT("set_alex_hpf"), INERT("set_alex_lpf"), INERT("set_hermeslite_writepointer"),
     INERT("clear_hermeslite_response"), INERT("pc_to_hermes"), INERT("pc_to_hermeslite_writequeue"), INERT("freedv_open"),

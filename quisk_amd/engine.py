@@ -60,6 +60,10 @@ def lib():
     L.qk_audio_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.qk_get_graph.argtypes = [vp, C.c_double, C.c_double, vp, C.c_int, dp]
     L.qk_graph_pending.argtypes = [vp]
+    L.qk_set_ssb_squelch.argtypes = [vp, C.c_int, C.c_int]
+    L.qk_set_auto_notch.argtypes = [vp, C.c_int, C.c_int]
+    L.qk_set_rit_freq.argtypes = [vp, C.c_int]
+    L.qk_is_squelch.argtypes = [vp, C.c_int]
     L.qk_set_stereo_route.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.qk_key_up.argtypes = [vp]
     L.qk_change_scan.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -182,6 +186,21 @@ class Engine:
     def set_kill_audio(self, on):
         """set_kill_audio (quisk.c:4364-4370)."""
         _check(self.L.qk_set_kill_audio(self.h, int(bool(on))))
+
+    def set_ssb_squelch(self, enabled, level):
+        """set_ssb_squelch (quisk.c:4356-4362)."""
+        _check(self.L.qk_set_ssb_squelch(self.h, int(enabled), int(level)))
+
+    def set_auto_notch(self, rx, on):
+        """set_auto_notch (quisk.c:4237-4244), per receiver."""
+        _check(self.L.qk_set_auto_notch(self.h, int(rx), int(on)))
+
+    def set_rit_freq(self, hz):
+        _check(self.L.qk_set_rit_freq(self.h, int(hz)))
+
+    def is_squelch(self, freq):
+        """IsSquelch (quisk.c:1231-1252)."""
+        return _check(self.L.qk_is_squelch(self.h, int(freq)))
 
     def set_stereo_route(self, rx, partner_rx, method):
         """Second-receiver routing (quisk.c:2410-2494): 1 = (rx, partner), 2 = (partner, rx), 3 = partner on both, 0 = off."""

@@ -117,6 +117,8 @@ def oracle():
     L.qko_rx_set_squelch.argtypes = [C.c_void_p, C.c_double]
     L.qko_rx_set_kill_audio.argtypes = [C.c_void_p, C.c_int]
     L.qko_rx_squelch_active.argtypes = [C.c_void_p]
+    L.qko_rx_set_ssb_squelch.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.qko_rx_set_auto_notch.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.qko_rx_process.argtypes = [C.c_void_p, cdp, C.c_int]
     L.qko_rx_pre_agc.argtypes = [C.c_void_p, cdp, C.c_int]
     L.qko_rx_agc.argtypes = [C.c_void_p, cdp, C.c_int]
@@ -191,6 +193,12 @@ class OracleRx:
 
     def set_kill_audio(self, on):
         self.L.qko_rx_set_kill_audio(self.h, int(on))
+
+    def set_ssb_squelch(self, enabled, level):
+        self.L.qko_rx_set_ssb_squelch(self.h, int(enabled), int(level))
+
+    def set_auto_notch(self, on, rit_freq=0):
+        self.L.qko_rx_set_auto_notch(self.h, int(on), int(rit_freq))
 
     def squelch_active(self):
         return self.L.qko_rx_squelch_active(self.h)
