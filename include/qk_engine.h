@@ -241,6 +241,26 @@ int quisk_cCplxSampleFilter(double *samples, int count, const double *coefs, int
 int quisk_ccfFilter(double *samples, int count, const double *cpx_coefs, int ntaps, int decim,
                     double *hist, int *phase);
 
+/* The remaining filter.c kernels as host-buffer drop-ins with explicit state (`hist` = the last ntaps - 1 input samples):
+ *   qk_cInterpolate   quisk_cInterpolate (filter.c:108-142): complex samples, real taps, x interp in place (the buffer holds
+ *                     count * interp complex samples); returns the output count
+ *   qk_dC_out_block   quisk_dC_out (filter.c:60-81) over a block: real samples through complex taps (as quisk_filt_tune makes
+ *                     them, filter.c:35-58), one complex output per input sample
+ *   qk_dD_out_block   quisk_dD_out (filter.c:303-322) over a block: real samples, real taps, in place
+ * The reference calls the last two once per sample (microphone.c:373-717); a block is the sensible unit for a GPU. */
+int qk_cInterpolate(double *samples, int count, const double *coefs, int ntaps, int interp, double *hist);
+int qk_dC_out_block(const double *samples, int count, const double *cpx_coefs, int ntaps, double *hist, double *out_complex);
+int qk_dD_out_block(double *samples, int count, const double *coefs, int ntaps, double *hist);
+
+/* read_rx_udp10 (quisk.c:3341-3550), the Hermes / Metis wire format as the engine's input: n_packets receive packets of 1032
+ * bytes (EF FE 01 06, sequence number, two 512-byte frames of sync 7F 7F 7F, C0..C4 and records of (1 + multirx_count) x
+ * 24-bit Q, I samples + 2 microphone bytes).  The packets go to the GPU as they are; a kernel de-interleaves the first
+ * receiver's samples (left-justified into int32, quisk.c:3516-3518) into the block that qk_process_samples_device then takes.
+ * sub_out_host (optional): [multirx_count][samples] complex doubles of the sub-receivers' streams, for their graph frames
+ * (quisk.c:3520-3527).  *read_errors counts bad sync bytes, *overrange the ADC overrange bits of C1 (quisk.c:3455-3460,
+ * 3496-3499); sockets, sequence numbers and the transmit side stay with the caller.  Returns the number of samples processed. */
+int qk_process_hermes(qk_engine *e, const void *packets, int n_packets, int multirx_count, double *sub_out_host, int *read_errors, int *overrange);
+
 /* No counterpart in the reference.  For callers that cannot allocate: code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  quisk_cCplxSampleFilter (above) with every buffer already in DEVICE memory:
  * samples (count complex, filtered in place), coefs (ntaps doubles), hist (ntaps - 1 complex, updated); *phase is a

@@ -92,6 +92,54 @@ static inline double ddot_real(const qko_dfir *f, int first, int step, int terms
 }
 #define RING_ADVANCE(f) do { if (++(f)->pos >= (f)->ntaps) (f)->pos = 0; } while (0)
 
+void qko_dc_out_block(const double *x, int n, qko_dfir *f, qko_cd *out)
+{   /* quisk_dC_out (filter.c:60-81), sample after sample: real samples through the complex taps of qko_filt_tune */
+    int i, k, j;
+    for (i = 0; i < n; i++) {
+        qko_cd acc = 0;
+        f->ring[f->pos] = x[i];
+        j = f->pos;
+        for (k = 0; k < f->ntaps; k++) {
+            acc += f->ring[j] * f->hc[k];
+            if (--j < 0) j = f->ntaps - 1;
+        }
+        RING_ADVANCE(f);
+        out[i] = acc;
+    }
+}
+void qko_dd_out_block(double *x, int n, qko_dfir *f)
+{   /* quisk_dD_out (filter.c:303-322), sample after sample */
+    int i;
+    for (i = 0; i < n; i++) {
+        f->ring[f->pos] = x[i];
+        x[i] = ddot_real(f, 0, 1, f->ntaps);
+        RING_ADVANCE(f);
+    }
+}
+void qko_hermes_unpack(const unsigned char *buf, int multirx_count, qko_cd *samp, qko_cd *sub, long sub_stride, int *nsamples)
+{   /* the record loop of read_rx_udp10 for one 1032-byte packet (quisk.c:3453, 3513-3531); samples are appended at *nsamples */
+    int start, i, j, index, xr, xi, n = *nsamples;
+    const int num_records = 504 / ((multirx_count + 1) * 6 + 2);
+    for (start = 11; start < 1000; start += 512) {
+        index = start + 5;
+        for (i = 0; i < num_records; i++) {
+            xi = (int)((unsigned)buf[index] << 24 | (unsigned)buf[index + 1] << 16 | (unsigned)buf[index + 2] << 8);
+            xr = (int)((unsigned)buf[index + 3] << 24 | (unsigned)buf[index + 4] << 16 | (unsigned)buf[index + 5] << 8);
+            samp[n] = xr + xi * I;
+            index += 6;
+            for (j = 0; j < multirx_count; j++) {
+                xi = (int)((unsigned)buf[index] << 24 | (unsigned)buf[index + 1] << 16 | (unsigned)buf[index + 2] << 8);
+                xr = (int)((unsigned)buf[index + 3] << 24 | (unsigned)buf[index + 4] << 16 | (unsigned)buf[index + 5] << 8);
+                if (sub) sub[(long)j * sub_stride + n] = xr + xi * I;
+                index += 6;
+            }
+            n++;
+            index += 2;
+        }
+    }
+    *nsamples = n;
+}
+
 int qko_cdecimate(qko_cd *x, int n, qko_cfir *f, int decim)
 {
     int i, nout = 0;

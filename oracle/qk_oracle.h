@@ -46,6 +46,10 @@ typedef struct {            /* struct quisk_dFilter, filter.h:12-21 */
     double *scratch; int nscratch;
 } qko_dfir;
 typedef struct { int toggle; qko_cd samples[22]; qko_cd center[11]; qko_cd *scratch; int nscratch; } qko_chb45; /* filter.h:23-29 */
+void qko_dc_out_block(const double *x, int n, qko_dfir *f, qko_cd *out);      /* quisk_dC_out, filter.c:60-81 */
+void qko_dd_out_block(double *x, int n, qko_dfir *f);                         /* quisk_dD_out, filter.c:303-322 */
+/* read_rx_udp10's record loop for one packet (quisk.c:3513-3531) */
+void qko_hermes_unpack(const unsigned char *buf, int multirx_count, qko_cd *samp, qko_cd *sub, long sub_stride, int *nsamples);
 typedef struct { int toggle; double samples[22]; double center[11]; double *scratch; int nscratch; } qko_dhb45; /* filter.h:31-37 */
 
 void qko_cfir_init(qko_cfir *f, const double *h, int ntaps);           /* filter.c:9-20 */

@@ -2480,6 +2480,100 @@ static int fir_dropin(double *samples, int count, const double *coefs, int ntaps
     return n_out;
 }
 
+// quisk_cInterpolate / quisk_dC_out / quisk_dD_out over host buffers with explicit state
+static int hist_dropin(const void *in, size_t in_elem, int count, const double *coefs, size_t coef_doubles, int ntaps, void *hist,
+                       void *out, size_t out_elem, size_t n_out, int kind, int L)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(QK_EHIP, "no HIP device: the engine has no CPU path");
+    const size_t nh = (size_t)ntaps - 1, ntot = nh + (size_t)count;
+    unsigned char *dx = nullptr, *dy = nullptr; double *dh = nullptr;
+    auto cleanup = [&]() { if (dx) hipFree(dx); if (dy) hipFree(dy); if (dh) hipFree(dh); };
+#define DROPCHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(QK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
+    DROPCHECK(hipMalloc(&dx, std::max<size_t>(ntot, 1) * in_elem));
+    DROPCHECK(hipMalloc(&dy, std::max<size_t>(n_out, 1) * out_elem));
+    DROPCHECK(hipMalloc(&dh, coef_doubles * sizeof(double)));
+    if (nh) DROPCHECK(hipMemcpy(dx, hist, nh * in_elem, hipMemcpyHostToDevice));
+    if (count) DROPCHECK(hipMemcpy(dx + nh * in_elem, in, (size_t)count * in_elem, hipMemcpyHostToDevice));
+    DROPCHECK(hipMemcpy(dh, coefs, coef_doubles * sizeof(double), hipMemcpyHostToDevice));
+    if (n_out > 0) {
+        const dim3 grid((unsigned)((n_out + 255) / 256));
+        if (kind == 0) hipLaunchKernelGGL(k_cinterp_interleaved, grid, dim3(256), 0, 0, (const double2 *)dx, (double2 *)dy, dh, ntaps, L, count);
+        else hipLaunchKernelGGL(k_dfir_out, grid, dim3(256), 0, 0, (const double *)dx, (double *)dy, dh, ntaps, count, kind == 2);
+        DROPCHECK(hipGetLastError());
+    }
+    std::vector<unsigned char> nhist(nh * in_elem);
+    if (nh) DROPCHECK(hipMemcpy(nhist.data(), dx + (ntot - nh) * in_elem, nh * in_elem, hipMemcpyDeviceToHost));
+    if (n_out > 0) DROPCHECK(hipMemcpy(out, dy, n_out * out_elem, hipMemcpyDeviceToHost));
+#undef DROPCHECK
+    if (nh) memcpy(hist, nhist.data(), nh * in_elem);
+    cleanup();
+    return (int)n_out;
+}
+
+int qk_cInterpolate(double *samples, int count, const double *coefs, int ntaps, int interp, double *hist)
+{
+    if (!samples || !coefs || !hist || count < 0 || ntaps < 1 || interp < 1) return fail(QK_EINVAL, "bad interpolator arguments");      // (nTaps / interp terms per phase: a remainder is left out, filter.c:130)
+    return hist_dropin(samples, sizeof(double2), count, coefs, (size_t)ntaps, ntaps, hist, samples, sizeof(double2), (size_t)count * interp, 0, interp);
+}
+int qk_dC_out_block(const double *samples, int count, const double *cpx_coefs, int ntaps, double *hist, double *out_complex)
+{
+    if (!samples || !cpx_coefs || !hist || !out_complex || count < 0 || ntaps < 1) return fail(QK_EINVAL, "bad filter arguments");
+    return hist_dropin(samples, sizeof(double), count, cpx_coefs, (size_t)2 * ntaps, ntaps, hist, out_complex, sizeof(double2), (size_t)count, 2, 1);
+}
+int qk_dD_out_block(double *samples, int count, const double *coefs, int ntaps, double *hist)
+{
+    if (!samples || !coefs || !hist || count < 0 || ntaps < 1) return fail(QK_EINVAL, "bad filter arguments");
+    return hist_dropin(samples, sizeof(double), count, coefs, (size_t)ntaps, ntaps, hist, samples, sizeof(double), (size_t)count, 1, 1);
+}
+
+int qk_process_hermes(qk_engine *e, const void *packets, int n_packets, int multirx_count, double *sub_out_host, int *read_errors, int *overrange)
+{
+    ENGINE_ENTER(e);
+    if (!packets || n_packets < 0 || multirx_count < 0 || multirx_count > 9) return fail(QK_EINVAL, "bad Hermes packet arguments");
+    const int nrx = multirx_count + 1;
+    const int num_records = 504 / (nrx * 6 + 2);                       // quisk.c:3367
+    const long long n = (long long)n_packets * 2 * num_records;
+    if (n > e->cfg.max_block) return fail(QK_ERANGE, "packets hold more samples than max_block");
+    // the bytes the host has to look at itself (quisk.c:3403, 3440-3460, 3496-3499): header, sync, the ADC overrange bit of C1
+    int errs = 0, over = 0;
+    const unsigned char *pk = static_cast<const unsigned char *>(packets);
+    for (int p = 0; p < n_packets; p++) {
+        const unsigned char *b = pk + (size_t)p * 1032;
+        if (b[0] != 0xEF || b[1] != 0xFE || b[2] != 0x01 || b[3] != 0x06) return fail(QK_EINVAL, "not a Hermes receive packet (EF FE 01 06)");
+        for (int start = 11; start < 1000; start += 512) {
+            if (b[start - 3] != 0x7F || b[start - 2] != 0x7F || b[start - 1] != 0x7F) errs++;
+            int dindex = b[start] >> 1;
+            if (!(dindex & 0x40)) dindex >>= 2;
+            if (dindex == 0 && (b[start + 1] & 0x01)) over++;
+        }
+    }
+    if (read_errors) *read_errors = errs;
+    if (overrange) *overrange = over;
+    if (n == 0) return process_device(e, e->d_in, 0) == QK_OK ? 0 : QK_EHIP;
+    SYNC_ALL(e);
+    const size_t bytes = (size_t)n_packets * 1032;
+    if (bytes > e->raw_cap) {
+        if (e->d_raw) hipFree(e->d_raw);
+        e->d_raw = nullptr;
+        e->raw_cap = std::max(bytes, (size_t)e->cfg.max_block * 8);
+        HIPCHECK(hipMalloc(&e->d_raw, e->raw_cap));
+    }
+    double2 *d_sub = nullptr;
+    if (sub_out_host && multirx_count > 0) HIPCHECK(hipMalloc(&d_sub, sizeof(double2) * (size_t)n * multirx_count));
+    HIPCHECK(hipMemcpyAsync(e->d_raw, packets, bytes, hipMemcpyHostToDevice, e->fe_stream));
+    hipLaunchKernelGGL(k_unpack_hermes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->fe_stream, e->d_raw, n_packets, nrx, num_records,
+                       e->d_in, d_sub, n);
+    if (d_sub) {
+        hipError_t ce = hipMemcpyAsync(sub_out_host, d_sub, sizeof(double2) * (size_t)n * multirx_count, hipMemcpyDeviceToHost, e->fe_stream);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(e->fe_stream);
+        hipFree(d_sub);
+        if (ce != hipSuccess) return fail(QK_EHIP, hipGetErrorString(ce));
+    }
+    int rc = process_device(e, e->d_in, (int)n);
+    return rc == QK_OK ? (int)n : rc;
+}
+
 // ---- the entry point that allocates nothing (include/qk_engine.h) ----
 // Staging for the in-place filter lives in a file-scope device array; each GPU holds its own copy at its own address,
 // looked up once per device (hipGetSymbolAddress) and used through that pointer only -- the array's name is a host-side

@@ -1776,3 +1776,62 @@ __global__ __launch_bounds__(256) void k_keyup_ramp(double2 *out, long long out_
     const double f = factor[i];
     out[(long long)rx * out_stride + i] = make_double2(v.x * f, v.y * f);
 }
+
+// ------------------------------------------------------------------------------------------------
+// The remaining filter.c kernels as stand-alone drop-ins (the transmit chain uses them, microphone.c:373-717):
+//   quisk_cInterpolate (filter.c:108-142): polyphase x L of complex samples with real taps, out[L i + j] = L sum_k h[j + k L] x[i - k]
+//   quisk_dC_out (filter.c:60-81): real samples through COMPLEX taps (quisk_filt_tune), one complex output per input
+//   quisk_dD_out (filter.c:303-322): real samples through real taps
+// x holds ntaps - 1 history samples followed by the new block.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cinterp_interleaved(const double2 *x, double2 *y, const double *h, int T, int L, int n_in)
+{
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_in * L) return;
+    const int i = o / L, j = o - i * L;
+    const double2 *p = x + (T - 1) + i;
+    double ar = 0.0, ai = 0.0;
+    const int terms = T / L;
+    for (int k = 0; k < terms; k++) {
+        const double2 v = p[-k]; const double c = h[j + k * L];
+        ar = fma(v.x, c, ar); ai = fma(v.y, c, ai);
+    }
+    y[o] = make_double2(ar * L, ai * L);
+}
+__global__ __launch_bounds__(256) void k_dfir_out(const double *x, double *y, const double *h, int T, int n, int cpx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double *p = x + (T - 1) + i;
+    if (cpx) {
+        const double2 *c = reinterpret_cast<const double2 *>(h);
+        double ar = 0.0, ai = 0.0;
+        for (int k = 0; k < T; k++) { const double v = p[-k]; ar = fma(v, c[k].x, ar); ai = fma(v, c[k].y, ai); }
+        reinterpret_cast<double2 *>(y)[i] = make_double2(ar, ai);
+    } else {
+        double a = 0.0;
+        for (int k = 0; k < T; k++) a = fma(p[-k], h[k], a);
+        y[i] = a;
+    }
+}
+// Hermes / Metis receive packets (read_rx_udp10, quisk.c:3341-3550): 1032 bytes = 8 header bytes and two 512-byte frames of
+// 3 sync bytes, 5 control bytes and num_records records of (1 + multirx_count) x (3 bytes Q, 3 bytes I, big endian, left-
+// justified into int32: quisk.c:3516-3518) followed by 2 microphone bytes.  Sample s of the packet stream goes to
+// out[s] (the first receiver's) and, for sub-receiver j, to sub[j * sub_stride + s].
+__global__ __launch_bounds__(256) void k_unpack_hermes(const unsigned char *pk, int n_packets, int nrx, int num_records, double2 *out,
+                                                       double2 *sub, long long sub_stride)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int per_packet = 2 * num_records;
+    if (s >= n_packets * per_packet) return;
+    const int p = s / per_packet, r = s - p * per_packet;
+    const int frame = r / num_records, rec = r - frame * num_records;
+    const unsigned char *b = pk + (long long)p * 1032 + 11 + 512 * frame + 5 + rec * (nrx * 6 + 2);
+    for (int j = 0; j < nrx; j++, b += 6) {
+        const int xi = (int)((unsigned)b[0] << 24 | (unsigned)b[1] << 16 | (unsigned)b[2] << 8);
+        const int xr = (int)((unsigned)b[3] << 24 | (unsigned)b[4] << 16 | (unsigned)b[5] << 8);
+        const double2 v = make_double2((double)xr, (double)xi);
+        if (j == 0) out[s] = v;
+        else if (sub) sub[(long long)(j - 1) * sub_stride + s] = v;
+    }
+}

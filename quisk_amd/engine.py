@@ -96,6 +96,10 @@ def lib():
     L.qk_debug_agc_passes.restype = C.c_longlong
     L.quisk_cCplxSampleFilter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip]
     L.quisk_ccfFilter.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip]
+    L.qk_cInterpolate.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp]
+    L.qk_dC_out_block.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
+    L.qk_dD_out_block.argtypes = [vp, C.c_int, vp, C.c_int, vp]
+    L.qk_process_hermes.argtypes = [vp, vp, C.c_int, C.c_int, vp, ip, ip]
     L.quisk_cCplxSampleFilter_noalloc.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip, vp]
     _lib = L
     return L
@@ -239,6 +243,18 @@ class Engine:
     def process_int(self, raw, nbytes_per_component, big_endian=False):
         buf = np.frombuffer(raw, dtype=np.uint8)
         _check(self.L.qk_process_samples_int(self.h, buf.ctypes.data, buf.size, nbytes_per_component, int(big_endian)))
+
+    def process_hermes(self, packets, multirx_count=0, want_sub=False):
+        """read_rx_udp10's wire format (quisk.c:3341-3550): `packets` = whole 1032-byte Hermes receive packets.
+        Returns (samples processed, read errors, overrange count, sub-receiver samples or None)."""
+        buf = np.frombuffer(packets, dtype=np.uint8)
+        npk = buf.size // 1032
+        nrec = 504 // ((multirx_count + 1) * 6 + 2)
+        sub = np.zeros((multirx_count, npk * 2 * nrec), dtype=np.complex128) if (want_sub and multirx_count) else None
+        err, over = C.c_int(0), C.c_int(0)
+        n = _check(self.L.qk_process_hermes(self.h, buf.ctypes.data, npk, int(multirx_count), sub.ctypes.data if sub is not None else None,
+                                            C.byref(err), C.byref(over)))
+        return n, err.value, over.value, sub
 
     def sync(self):
         _check(self.L.qk_sync(self.h))

@@ -100,6 +100,9 @@ def oracle():
     L.qko_ddecimate.argtypes = [ddp, C.c_int, P(ODFir), C.c_int]
     L.qko_dinterpolate.argtypes = [ddp, C.c_int, P(ODFir), C.c_int]
     L.qko_dfilter.argtypes = [ddp, C.c_int, P(ODFir)]
+    L.qko_dc_out_block.argtypes = [ddp, C.c_int, P(ODFir), cdp]
+    L.qko_dd_out_block.argtypes = [ddp, C.c_int, P(ODFir)]
+    L.qko_hermes_unpack.argtypes = [C.c_void_p, C.c_int, cdp, C.c_void_p, C.c_long, P(C.c_int)]
     L.qko_cinterpdecim.argtypes = [cdp, C.c_int, P(OCFir), C.c_int, C.c_int]
     L.qko_cdecim2hb45.argtypes = [cdp, C.c_int, P(OCHB)]
     L.qko_cinterp2hb45.argtypes = [cdp, C.c_int, P(OCHB)]
@@ -253,6 +256,10 @@ class RDFilter(C.Structure):      # struct quisk_dFilter, filter.h:12-21
                 ("decim_index", C.c_int), ("dSamples", C.c_void_p), ("ptdSamp", C.c_void_p), ("dBuf", C.c_void_p)]
 
 
+class RCd(C.Structure):           # complex double returned by value
+    _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+
 class RCHB(C.Structure):          # struct quisk_cHB45Filter, filter.h:23-29
     _fields_ = [("cBuf", C.c_void_p), ("nBuf", C.c_int), ("toggle", C.c_int),
                 ("samples", C.c_double * 44), ("center", C.c_double * 22)]
@@ -284,6 +291,10 @@ def ref():
     L.quisk_dDecimate.argtypes = [ddp, C.c_int, P(RDFilter), C.c_int]
     L.quisk_dInterpolate.argtypes = [ddp, C.c_int, P(RDFilter), C.c_int]
     L.quisk_dFilter.argtypes = [ddp, C.c_int, P(RDFilter)]
+    L.quisk_dD_out.argtypes = [C.c_double, P(RDFilter)]
+    L.quisk_dD_out.restype = C.c_double
+    L.quisk_dC_out.argtypes = [C.c_double, P(RDFilter)]
+    L.quisk_dC_out.restype = RCd
     L.quisk_cInterpDecim.argtypes = [cdp, C.c_int, P(RCFilter), C.c_int, C.c_int]
     L.quisk_cDecim2HB45.argtypes = [cdp, C.c_int, P(RCHB)]
     L.quisk_cInterp2HB45.argtypes = [cdp, C.c_int, P(RCHB)]

@@ -137,6 +137,23 @@ def main():
     out["dinterp2hb45:in"] = x
     out["dinterp2hb45:out"] = run_blocks(lambda b, n: R.quisk_dInterp2HB45(b, n, C.byref(hb3)), x, cap_mult=2)
 
+    # the per-sample filters quisk_dD_out and quisk_dC_out (the latter after quisk_filt_tune)
+    x = np.round(rng.standard_normal(N) * 2.0 ** 24)
+    f = dfilter("quiskAudio24p6Coefs")
+    out["dd_out:qk_h_aud24p6_36:in"] = x
+    out["dd_out:qk_h_aud24p6_36:out"] = np.array([R.quisk_dD_out(float(v), C.byref(f)) for v in x])
+    for upper in (1, 0):
+        x = np.round(rng.standard_normal(N) * 2.0 ** 24)
+        f = dfilter("quiskAudio24p3Coefs")
+        R.quisk_filt_tune(C.byref(f), 1650.0 / 48000, upper)
+        key = "dc_out:qk_h_aud24p3_100:%d" % upper
+        vals = [R.quisk_dC_out(float(v), C.byref(f)) for v in x]
+        out[key + ":in"] = x
+        out[key + ":out"] = np.array([complex(v.re, v.im) for v in vals])
+        nt = f.nTaps
+        cc = np.ctypeslib.as_array(C.cast(f.cpxCoefs, C.POINTER(C.c_double)), shape=(2 * nt,)).copy()
+        out[key + ":coefs"] = cc[0::2] + 1j * cc[1::2]
+
     np.savez_compressed(os.path.join(HERE, "filter_kernels.npz"), **out)
     np.savez_compressed(os.path.join(HERE, "coef_tables.npz"), **tabs)
 

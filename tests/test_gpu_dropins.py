@@ -71,3 +71,100 @@ def test_integer_sample_input(nbytes, big):
         ref.process(xq[i * block:(i + 1) * block])
         assert np.array_equal(eng.audio(0), ref.audio(0))
     eng.close(); ref.close()
+
+
+def test_interpolator_and_per_sample_filter_dropins():
+    """qk_cInterpolate (quisk_cInterpolate, filter.c:108-142), qk_dD_out_block and qk_dC_out_block (quisk_dD_out / quisk_dC_out,
+    filter.c:303-322, 60-81) against the compiled reference's golden vectors, in two unequal blocks (carried history)."""
+    L = lib()
+    # x 3 interpolation of complex samples
+    key = "cinterpolate:qk_h_aud24p3_100:3"
+    h = np.ascontiguousarray(B.oracle_table("qk_h_aud24p3_100"))
+    x = G[key + ":in"]
+    hist = np.zeros(2 * (len(h) - 1))
+    outs = []
+    for blk in (x[:SPLIT], x[SPLIT:]):
+        buf = np.zeros(3 * len(blk) + 8, dtype=np.complex128); buf[:len(blk)] = blk
+        m = L.qk_cInterpolate(buf.ctypes.data, len(blk), h.ctypes.data, len(h), 3, hist.ctypes.data)
+        assert m == 3 * len(blk), L.qk_last_error()
+        outs.append(buf[:m].copy())
+    got, want = np.concatenate(outs), G[key + ":out"]
+    assert got.shape == want.shape and np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-13
+    # real taps on real samples
+    key = "dd_out:qk_h_aud24p6_36"
+    h = np.ascontiguousarray(B.oracle_table("qk_h_aud24p6_36"))
+    x = np.array(G[key + ":in"], copy=True)
+    hist = np.zeros(len(h) - 1)
+    a, b = np.ascontiguousarray(x[:SPLIT]), np.ascontiguousarray(x[SPLIT:])
+    assert L.qk_dD_out_block(a.ctypes.data, len(a), h.ctypes.data, len(h), hist.ctypes.data) == len(a)
+    assert L.qk_dD_out_block(b.ctypes.data, len(b), h.ctypes.data, len(h), hist.ctypes.data) == len(b)
+    got, want = np.concatenate([a, b]), G[key + ":out"]
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-13
+    # complex taps on real samples, both sidebands
+    for upper in (1, 0):
+        key = "dc_out:qk_h_aud24p3_100:%d" % upper
+        cc = np.ascontiguousarray(G[key + ":coefs"])
+        x = np.ascontiguousarray(G[key + ":in"])
+        hist = np.zeros(len(cc) - 1)
+        out = np.zeros(len(x), dtype=np.complex128)
+        a, b = np.ascontiguousarray(x[:SPLIT]), np.ascontiguousarray(x[SPLIT:])
+        oa, ob = np.zeros(len(a), np.complex128), np.zeros(len(b), np.complex128)
+        assert L.qk_dC_out_block(a.ctypes.data, len(a), cc.ctypes.data, len(cc), hist.ctypes.data, oa.ctypes.data) == len(a)
+        assert L.qk_dC_out_block(b.ctypes.data, len(b), cc.ctypes.data, len(cc), hist.ctypes.data, ob.ctypes.data) == len(b)
+        got, want = np.concatenate([oa, ob]), G[key + ":out"]
+        assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-13
+
+
+@pytest.mark.parametrize("multirx", [0, 2, 5])
+def test_hermes_packets_as_input(multirx):
+    """read_rx_udp10's wire format (quisk.c:3341-3550): whole 1032-byte packets go to the GPU, a kernel de-interleaves the
+    24-bit big-endian Q, I records of the first receiver (and the sub-receivers' streams), then the block runs as usual;
+    against the oracle's restatement of the record loop and the engine fed the unpacked samples."""
+    fs = 192000
+    nrx = multirx + 1
+    nrec = 504 // (nrx * 6 + 2)
+    npk = 40
+    rng = np.random.default_rng(7 + multirx)
+    x = make_iq(npk * 2 * nrec, fs, [30000], [3], 5)
+    pk = bytearray()
+    k = 0
+    for p in range(npk):
+        pk += bytes([0xEF, 0xFE, 0x01, 0x06]) + int(p).to_bytes(4, "big")
+        for fr in range(2):
+            sync = [0x7F, 0x7F, 0x7F] if not (p == 3 and fr == 1) else [0x7F, 0x00, 0x7F]      # one bad sync byte
+            c0, c1 = 0x00, (0x01 if p == 5 and fr == 0 else 0x00)                             # one ADC overrange report
+            frame = bytearray(sync + [c0, c1, 0, 0, 0])
+            for r in range(nrec):
+                for j in range(nrx):
+                    if j == 0:
+                        q, i = int(x[k].imag) >> 8, int(x[k].real) >> 8
+                    else:
+                        q, i = (int(v) for v in rng.integers(-2 ** 23, 2 ** 23, 2))
+                    frame += int(q).to_bytes(3, "big", signed=True) + int(i).to_bytes(3, "big", signed=True)
+                frame += b"\\x12\\x34"[:2] if False else bytes(2)
+                k += 1
+            frame += bytes(512 - len(frame))
+            pk += frame
+    pk = bytes(pk)
+    assert len(pk) == 1032 * npk
+    # the oracle's record loop
+    LO = B.oracle()
+    samp = np.zeros(npk * 2 * nrec, dtype=np.complex128)
+    sub = np.zeros((max(multirx, 1), len(samp)), dtype=np.complex128)
+    cnt = C.c_int(0)
+    raw = np.frombuffer(pk, dtype=np.uint8)
+    for p in range(npk):
+        LO.qko_hermes_unpack(raw[p * 1032:].ctypes.data, multirx, samp, sub.ctypes.data, len(samp), C.byref(cnt))
+    assert cnt.value == len(samp)
+    assert np.array_equal(samp.real, np.floor(x.real / 256) * 256) and np.array_equal(samp.imag, np.floor(x.imag / 256) * 256)
+    from _rxsetup import configure_engine
+    eng = Engine(fs, n_receivers=1, max_block=len(samp))
+    ref = Engine(fs, n_receivers=1, max_block=len(samp))
+    configure_engine(eng, [3], [30000]); configure_engine(ref, [3], [30000])
+    n, errs, over, gsub = eng.process_hermes(pk, multirx, want_sub=True)
+    ref.process(samp)
+    assert (n, errs, over) == (len(samp), 1, 1)
+    assert np.array_equal(eng.audio(0), ref.audio(0))
+    if multirx:
+        assert np.array_equal(gsub, sub[:multirx])
+    eng.close(); ref.close()

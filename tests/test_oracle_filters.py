@@ -148,3 +148,37 @@ def test_live_reference_long_stream_ragged_blocks():
         ma = L.qko_cdecimate(a, na, C.byref(fo), 3); mb = R.quisk_cDecimate(b, nb, C.byref(fr), 3)
         assert ma == mb
         _same(a[:ma], b[:mb])
+
+
+def test_dd_out_per_sample_filter():
+    """quisk_dD_out (filter.c:303-322) against the compiled reference's per-sample outputs."""
+    L = B.oracle()
+    key = "dd_out:qk_h_aud24p6_36"
+    h, hp = _tab("qk_h_aud24p6_36")
+    f = B.ODFir()
+    L.qko_dfir_init(C.byref(f), hp, len(h))
+    x = np.array(G[key + ":in"], copy=True)
+    L.qko_dd_out_block(x[:SPLIT], SPLIT, C.byref(f))
+    tail = np.ascontiguousarray(x[SPLIT:])
+    L.qko_dd_out_block(tail, len(tail), C.byref(f))
+    _same(np.concatenate([x[:SPLIT], tail]), G[key + ":out"])
+    L.qko_dfir_free(C.byref(f))
+
+
+@pytest.mark.parametrize("upper", [1, 0])
+def test_dc_out_after_filt_tune(upper):
+    """quisk_dC_out (filter.c:60-81) with the complex taps of quisk_filt_tune (filter.c:35-58)."""
+    L = B.oracle()
+    key = "dc_out:qk_h_aud24p3_100:%d" % upper
+    h, hp = _tab("qk_h_aud24p3_100")
+    f = B.ODFir()
+    L.qko_dfir_init(C.byref(f), hp, len(h))
+    L.qko_filt_tune(C.byref(f), 1650.0 / 48000, upper)
+    x = np.ascontiguousarray(G[key + ":in"])
+    out = np.zeros(len(x), dtype=np.complex128)
+    L.qko_dc_out_block(x[:SPLIT], SPLIT, C.byref(f), out[:SPLIT])
+    rest = np.zeros(len(x) - SPLIT, dtype=np.complex128)
+    L.qko_dc_out_block(np.ascontiguousarray(x[SPLIT:]), len(x) - SPLIT, C.byref(f), rest)
+    out[SPLIT:] = rest
+    _same(out, G[key + ":out"])
+    L.qko_dfir_free(C.byref(f))
