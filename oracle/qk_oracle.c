@@ -499,6 +499,7 @@ struct qko_rx {
     int planned_rate, d2, d3, d5;
     qko_chb45 hb[5];
     qko_cfir sdriq111, sdriq53, sdriq133, sdriq167, sdriq185, dec3[3], dec5, dec5b, dec5s, dec2last, rs65;
+    qko_cfir rs45; int own_rs45;                         /* a resampler filter of its own instead of the shared filtDecim5S (test aid, see qko_rx_set_own_resampler) */
     int decim_srate, filter_srate;
     /* quisk_process_demodulate Storage, quisk.c:1730-1747 */
     qko_cd fm_1; double dc_remove, fm_a0, fm_a1, fm_b1, fm_x1, fm_y1;
@@ -685,7 +686,7 @@ qko_rx *qko_rx_new(int sample_rate, int playback_rate)
     CI(sdriq111, qk_h_sdriq111_114); CI(sdriq53, qk_h_sdriq53_55); CI(sdriq133, qk_h_sdriq133_136);
     CI(sdriq167, qk_h_sdriq167_174); CI(sdriq185, qk_h_sdriq185_189);
     for (i = 0; i < 3; i++) CI(dec3[i], qk_h_dec3_147);
-    CI(dec5, qk_h_dec5_245); CI(dec5b, qk_h_dec5_245); CI(dec5s, qk_h_dec5_245);
+    CI(dec5, qk_h_dec5_245); CI(dec5b, qk_h_dec5_245); CI(dec5s, qk_h_dec5_245); CI(rs45, qk_h_dec5_245);
     CI(dec2last, qk_h_dec2_98); CI(rs65, qk_h_rs65_125);
     DI(aud24p3, qk_h_aud24p3_100); DI(aud24p4, qk_h_aud24p4_50); DI(aud12p2, qk_h_aud24p4_50);
     DI(aud24p6, qk_h_aud24p6_36); DI(fmhp, qk_h_fmhp_309);
@@ -716,7 +717,7 @@ void qko_rx_free(qko_rx *rx)
     qko_cfir_free(&rx->sdriq111); qko_cfir_free(&rx->sdriq53); qko_cfir_free(&rx->sdriq133);
     qko_cfir_free(&rx->sdriq167); qko_cfir_free(&rx->sdriq185);
     for (i = 0; i < 3; i++) qko_cfir_free(&rx->dec3[i]);
-    qko_cfir_free(&rx->dec5); qko_cfir_free(&rx->dec5b); qko_cfir_free(&rx->dec5s);
+    qko_cfir_free(&rx->dec5); qko_cfir_free(&rx->dec5b); qko_cfir_free(&rx->dec5s); qko_cfir_free(&rx->rs45);
     qko_cfir_free(&rx->dec2last); qko_cfir_free(&rx->rs65); qko_cfir_free(&rx->dem_dec2);
     qko_dfir_free(&rx->aud24p3); qko_dfir_free(&rx->aud24p4); qko_dfir_free(&rx->aud12p2);
     qko_dfir_free(&rx->aud24p6); qko_dfir_free(&rx->fmhp);
@@ -729,6 +730,10 @@ void qko_rx_free(qko_rx *rx)
     free(rx);
 }
 
+/* The reference runs the resampler's second stage on filtDecim5S, the state object of the third /5 stage (quisk.c:1713): at
+ * rates whose plan has three /5 stages the two filters then overwrite each other's history and counters.  on = 1 gives the
+ * resampler a state of its own (what the plan means; the GPU engine's stages never share state). */
+void qko_rx_set_own_resampler(qko_rx *rx, int on) { rx->own_rs45 = on; }
 void qko_rx_set_squelch(qko_rx *rx, double level_db) { rx->squelch_level = level_db; }       /* set_squelch, quisk.c:4348 */
 void qko_rx_set_kill_audio(qko_rx *rx, int on) { rx->kill_audio = on; }                        /* set_kill_audio, quisk.c:4364 */
 int  qko_rx_squelch_active(const qko_rx *rx) { return rx->sq_active; }
@@ -810,7 +815,7 @@ int qko_rx_decimate(qko_rx *rx, qko_cd *x, int n)
     if (rx->decim_srate >= 50000) {                      /* 24/25 resampler; the second stage shares dec5s (quisk.c:1713) */
         rx->decim_srate = rx->decim_srate * 24 / 25;
         n = qko_cinterpdecim(x, n, &rx->rs65, 6, 5);
-        n = qko_cinterpdecim(x, n, &rx->dec5s, 4, 5);
+        n = qko_cinterpdecim(x, n, rx->own_rs45 ? &rx->rs45 : &rx->dec5s, 4, 5);
     }
     return n;
 }

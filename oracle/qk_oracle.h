@@ -102,6 +102,7 @@ void qko_rx_agc(qko_rx *rx, qko_cd *x, int n);
 void qko_rx_mix(qko_rx *rx, qko_cd *x, int n);                         /* quisk.c:2350-2361 */
 int  qko_rx_decimate(qko_rx *rx, qko_cd *x, int n);                    /* quisk.c:1549-1722 */
 int  qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *audio, int n);   /* quisk.c:1724-2020 */
+void qko_rx_set_own_resampler(qko_rx *rx, int on);                   /* see qk_oracle.c: quisk.c:1713 shares filtDecim5S */
 void qko_rx_set_ssb_squelch(qko_rx *rx, int enabled, int level);     /* set_ssb_squelch, quisk.c:4356-4362 */
 void qko_rx_set_auto_notch(qko_rx *rx, int on, int rit_freq);        /* set_auto_notch, quisk.c:4237-4244 (bank 0 only there) */
 int  qko_rx_decim_srate(const qko_rx *rx);

@@ -399,9 +399,8 @@ static int build_front(qk_engine *e)
         for (int i = 0; i < d3; i++) r /= 3;
         for (int i = 0; i < d5; i++) r /= 5;
         resample = r >= 50000;
-        if (resample && d5 >= 3)
-            return fail(QK_EUNSUPPORTED, "sample rate whose plan uses three /5 stages and the 24/25 resampler "
-                                         "(the reference shares one filter state between them, quisk.c:1713)");
+        // (three /5 stages and the 24/25 resampler: the reference runs the resampler's second stage on the state object of the
+        // third /5 stage, quisk.c:1713, and the two overwrite each other; here every stage has a state of its own)
         break;
     }
     }

@@ -121,6 +121,7 @@ def oracle():
     L.qko_rx_set_kill_audio.argtypes = [C.c_void_p, C.c_int]
     L.qko_rx_squelch_active.argtypes = [C.c_void_p]
     L.qko_rx_set_ssb_squelch.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.qko_rx_set_own_resampler.argtypes = [C.c_void_p, C.c_int]
     L.qko_rx_set_auto_notch.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.qko_rx_process.argtypes = [C.c_void_p, cdp, C.c_int]
     L.qko_rx_pre_agc.argtypes = [C.c_void_p, cdp, C.c_int]

@@ -276,3 +276,28 @@ def test_long_run_mixer_drift():
     pr = _stream(fs, [3], [345678], blocks, 1002)
     assert pr.samples == 16 * 32768
     pr.check()
+
+
+def test_three_fifths_and_the_resampler():
+    """6.4 Msps: the plan is three /5 stages (51 200) and the 24/25 resampler.  The reference runs the resampler's second
+    stage on filtDecim5S, the state object of the third /5 stage (quisk.c:1713), so that the two overwrite each other's
+    history and counters; the engine's stages have states of their own.  Parity is therefore against the oracle with
+    that one sharing undone (qko_rx_set_own_resampler) -- and the oracle as the reference has it is shown to differ."""
+    fs = 6400000
+    sizes = [640000, 333333, 640000, 640000]
+    x = make_iq(sum(sizes), fs, [1234567, -2000000], [3, 4], 71)
+    eng = Engine(fs, n_receivers=2, max_block=max(sizes))
+    pr = PairRunner(eng, [3, 4], [1234567, -2000000])
+    shared = make_oracle_rx(fs, 3, 1234567)
+    for o in pr.oras:
+        o.L.qko_rx_set_own_resampler(o.h, 1)
+    pos, differs = 0, False
+    for n in sizes:
+        blk = x[pos:pos + n]; pos += n
+        pr.step(blk)
+        a = shared.process_parts(blk)[0]
+        b = pr.log[0]["po"][-1]
+        differs = differs or (len(a) == len(b) and len(a) > 0 and float(np.max(np.abs(a.real - b))) > 1e-6 * max(float(np.max(np.abs(b))), 1.0))
+    pr.close(); shared.close()
+    pr.check()
+    assert differs
