@@ -23,6 +23,17 @@ extern "C" void qk_phase_tables(double pre, double pim, double *C, double *B, do
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+// Flags of the events that order one stream behind another (QK_EVENT_TIMING=1: events with time stamps, for experiments).
+static int dbg_nowait()
+{
+    static const int v = [] { const char *t = getenv("QK_DBG_NOWAIT"); return t ? atoi(t) : 0; }();
+    return v;
+}
+static unsigned sync_event_flags()
+{
+    static const int timing = [] { const char *v = getenv("QK_EVENT_TIMING"); return v ? atoi(v) : 0; }();
+    return timing ? hipEventDefault : hipEventDisableTiming;
+}
 #define HIPCHECK(expr)                                                                                   \
     do {                                                                                                 \
         hipError_t _e = (expr);                                                                          \
@@ -507,7 +518,7 @@ static int build_class(qk_engine *e, int cl)
         for (auto &fs : c.frac_slot) {
             HIPCHECK(hipHostMalloc(&fs.idx, sizeof(int) * c.frac_cap, hipHostMallocMapped));
             HIPCHECK(hipHostMalloc(&fs.pos, sizeof(double) * c.frac_cap, hipHostMallocMapped));
-            HIPCHECK(hipEventCreateWithFlags(&fs.ev, hipEventDisableTiming));
+            HIPCHECK(hipEventCreateWithFlags(&fs.ev, sync_event_flags()));
         }
         c.frac_dindex = 1.0;                                         // dindex = 1 (quisk.c:575)
     }
@@ -719,7 +730,7 @@ static int init_receivers(qk_engine *e)
     e->keyup_cap = (int)(cfg.playback_rate * 5e-3) + 8;
     HIPCHECK(hipHostMalloc(&e->h_keyup, sizeof(double) * e->keyup_cap, hipHostMallocMapped));
     HIPCHECK(hipHostMalloc(&e->h_keyup_counts, sizeof(int) * nrx, hipHostMallocMapped));
-    HIPCHECK(hipEventCreateWithFlags(&e->ev_keyup, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_keyup, sync_event_flags()));
     HIPCHECK(hipMalloc(&e->d_gains, nrx * e->gain_stride * sizeof(double)));
     HIPCHECK(hipMalloc(&e->d_agc_mag, nrx * e->gain_stride * sizeof(double)));
     if (e->apply_stream) {
@@ -772,16 +783,16 @@ static int engine_init(qk_engine *e)
     if (const char *v = getenv("QK_APPLY_STREAM")) apply_own = atoi(v) != 0;
     if (apply_own) {
         HIPCHECK(hipStreamCreateWithFlags(&e->apply_stream, hipStreamNonBlocking));
-        HIPCHECK(hipEventCreateWithFlags(&e->ev_gain, hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&e->ev_gain, sync_event_flags()));
     }
     HIPCHECK(hipStreamCreateWithFlags(&e->fe_stream, hipStreamNonBlocking));
-    HIPCHECK(hipEventCreateWithFlags(&e->ev_fe, hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&e->ev_fe2, hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&e->ev_read[0], hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&e->ev_read[1], hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&e->ev_chain, hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&e->ev_agc[0], hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&e->ev_agc[1], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_fe, sync_event_flags()));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_fe2, sync_event_flags()));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_read[0], sync_event_flags()));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_read[1], sync_event_flags()));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_chain, sync_event_flags()));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_agc[0], sync_event_flags()));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_agc[1], sync_event_flags()));
     e->nrx = cfg.n_receivers;
     // coefficient tables
     DevTables T;
@@ -1552,7 +1563,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     const int q = e->fe_blocks & 1;
     if (fe_writes) {
         std::swap(F.streams[0].d, F.front_alt);
-        if (e->read_pending[q]) HIPCHECK(hipStreamWaitEvent(e->fe_stream, e->ev_read[q], 0));
+        if (e->read_pending[q] && !(dbg_nowait() & 1)) HIPCHECK(hipStreamWaitEvent(e->fe_stream, e->ev_read[q], 0));
     }
     fa.out = F.streams[0].view();
     {
@@ -1624,7 +1635,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     //      block's front end and FIR chain instead of in front of them ----
     const int par = (int)(e->pipe_blocks & 1);
     HIPCHECK(hipEventRecord(e->ev_chain, e->stream));
-    HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_chain, 0));
+    if (!(dbg_nowait() & 4)) HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_chain, 0));
     if (fe_writes) {
         HIPCHECK(hipEventRecord(e->ev_read[q], e->stream));
         e->read_pending[q] = true;
@@ -1695,7 +1706,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         add_tails(ta, F, 0);        // stream 0 is carried by the head copy
         if (ta.count) hipLaunchKernelGGL(k_save_tails, dim3(ta.count, 2, e->nrx), dim3(256), 0, e->stream, ta);
         // the play streams' tails go into the twin buffers, which the previous block's AGC pass may still be reading
-        if (e->agc_pending) HIPCHECK(hipStreamWaitEvent(e->stream, e->ev_agc[par ^ 1], 0));
+        if (e->agc_pending && !(dbg_nowait() & 2)) HIPCHECK(hipStreamWaitEvent(e->stream, e->ev_agc[par ^ 1], 0));
         for (int cl = 0; cl < CL_COUNT; cl++) {
             Chain &c = e->cls_chain[cl];
             const int nl = (int)c.members.size();

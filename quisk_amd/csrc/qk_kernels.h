@@ -154,8 +154,11 @@ __global__ __launch_bounds__(256) void k_mixhist_update(FrontArgs a, double2 *hi
 // a busy one.
 // ------------------------------------------------------------------------------------------------
 #define FW_CHUNK 384
+#ifndef FE_WAVES_PER_EU
+#define FE_WAVES_PER_EU 2
+#endif
 struct FwLayout {
-    static __host__ __device__ constexpr int sub(int s) { return (FW_CHUNK >> (s + 1)) + FE_HIST + 14; }
+    static __host__ __device__ constexpr int sub(int s) { return (FW_CHUNK >> (s + 1)) + FE_HIST + (s == 2 ? 16 : s == 4 ? 18 : 14); }   // (pads chosen so that a stage's stores into the next level's E and O arrays fall on disjoint banks)
     static __host__ __device__ constexpr int level_off(int s) { int o = 0; for (int i = 0; i < s; i++) o += 4 * sub(i); return o; }
     static __host__ __device__ constexpr int total(int S) { return level_off(S) + 16; }
     static __host__ __device__ constexpr int R(int s) { return s == 0 ? 6 : s == 1 ? 3 : s == 2 ? 2 : 1; }
@@ -205,18 +208,30 @@ __device__ __forceinline__ void hb45_out(const T *__restrict__ O, const T *__res
 }
 
 // carry the last 22 entries of the four polyphase arrays of level s to their front (88 doubles: lanes 0..43
-// move two each).  n_new = samples added per array this chunk.  One wave: every lane's reads are issued before
-// any lane's writes (same instruction stream, in-order LDS), so no barrier is needed even when they overlap.
+// move two each).  n_new = samples added per array this chunk.  One wave: the LDS serves a wave's instructions in
+// the order they were issued, so the reads of every lane come before the writes of any lane without a barrier, and
+// the two halves can sit apart: the reads are issued in front of the next stage's window reads, the writes behind
+// that stage's stores, and nobody waits for the carry alone.
 template <class T>
-__device__ __forceinline__ void fw_carry(T *smem, int s, int n_new, int lane)
+__device__ __forceinline__ void fw_carry_load(const T *smem, int s, int n_new, int lane, T (&v)[2])
+{
+    const int l = lane < 44 ? lane : 43;
+    const int sub = l / 11, i = (l % 11) * 2;               // 4 sub-arrays x 11 pairs
+    const T *arr = smem + FwLayout::level_off(s) + sub * FwLayout::sub(s) + (sub & 1);
+    v[0] = arr[n_new + i]; v[1] = arr[n_new + i + 1];
+}
+template <class T>
+__device__ __forceinline__ void fw_carry_store(T *smem, int s, int lane, const T (&v)[2])
 {
     if (lane < 44) {
-        const int sub = lane / 11, i = (lane % 11) * 2;         // 4 sub-arrays x 11 pairs
+        const int sub = lane / 11, i = (lane % 11) * 2;
         T *arr = smem + FwLayout::level_off(s) + sub * FwLayout::sub(s) + (sub & 1);
-        const T v0 = arr[n_new + i], v1 = arr[n_new + i + 1];
-        arr[i] = v0; arr[i + 1] = v1;
+        arr[i] = v[0]; arr[i + 1] = v[1];
     }
 }
+// Orders the wave's own LDS traffic for the compiler only: a one-wave workgroup needs neither s_barrier nor a drained
+// LDS queue between a stage's stores and the next stage's reads.
+#define FW_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 template <class T, int S, int s>
 __device__ __forceinline__ void fw_stage(T *smem, int c, int lane, bool emit, double *out0, double *out1, long long obase, long long dummy,
@@ -266,7 +281,7 @@ __device__ __forceinline__ void fw_stage(T *smem, int c, int lane, bool emit, do
 }
 
 template <int S, class T = double>
-__global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FE_WAVES_PER_EU, FE_WAVES_PER_EU))) void k_frontend_wave(FrontArgs a)
 {
     __shared__ __attribute__((aligned(16))) T smem[FwLayout::total(S)];
     const int rx = blockIdx.y, lane = threadIdx.x;
@@ -280,21 +295,24 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
     const long long g_lo = a.g_lo0 + (long long)span * a.span_len;
     if (g_lo >= a.g_end) break;
     const long long g_hi = (g_lo + a.span_len < a.g_end) ? g_lo + a.span_len : a.g_end;
-    __syncthreads();
+    FW_SYNC();
     for (int i = lane; i < FwLayout::level_off(S); i += 64) smem[i] = T(0);
     long long pos = g_lo - W;
     T *E0 = fw_arr(smem, 0, 0, 0), *O0 = fw_arr(smem, 0, 0, 1);
     T *E1 = fw_arr(smem, 0, 1, 0), *O1 = fw_arr(smem, 0, 1, 1);
-    // a lane's six samples of a chunk have the same parity as the lane
-    T *d0 = (lane & 1) ? O0 : E0, *d1 = (lane & 1) ? O1 : E1;
-    const int dofs = FE_HIST + (lane & 1) + (lane >> 1);
+    // Lanes 0..31 take the even samples of each 64, lanes 32..63 the odd ones (sample li + 64 it): a 16-lane store
+    // group then writes 16 consecutive doubles of ONE polyphase array -- all 32 store banks once.  (Lane = sample
+    // put even and odd lanes of a group on two arrays whose bank ranges overlapped: 2-way on every mixer store.)
+    const int li = ((lane & 31) << 1) | (lane >> 5);
+    T *d0 = (lane >> 5) ? O0 : E0, *d1 = (lane >> 5) ? O1 : E1;
+    const int dofs = FE_HIST + (lane >> 5) + (lane & 31);
     // The lane's mixer phasor: exact (from the tables) at its first in-block sample, then advanced by phase^64
     // from sample to sample of the lane (64 apart).  The recurrence runs over one span only (a few hundred
     // steps, ~1e-14 of rounding), then the next span starts from the tables again.
     const double2 P64 = a.mt.tabB[rx * 64 + 1];
     double2 w = make_double2(1.0, 0.0);
     {
-        long long kf = pos - a.N0 + lane;                // block-relative index of the lane's first sample
+        long long kf = pos - a.N0 + li;                // block-relative index of the lane's first sample
         if (kf < 0) kf += ((-kf + 63) >> 6) << 6;        // first one inside this block (same lane)
         if (mix) w = mix_w(a.mt, rx, kf);
     }
@@ -308,7 +326,7 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
     auto fetch = [&](long long p, int c) {
         const long long k0 = p - a.N0;
         if (k0 >= 0 && c == FW_CHUNK) {          // whole chunk inside this block: no clamps, no validity bits
-            const double2 *src = a.x + k0 + lane;
+            const double2 *src = a.x + k0 + li;
 #pragma unroll
             for (int it = 0; it < NIT; it++) xv[it] = src[64 * it];
             okbits = (1u << NIT) - 1;
@@ -317,7 +335,7 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
         okbits = 0;
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            const int i = lane + 64 * it;
+            const int i = li + 64 * it;
             const long long k = k0 + i;
             const long long hi = k + a.H;
             const bool in_blk = k >= 0;
@@ -333,7 +351,7 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
     };
     int c = chunk_len(pos);
     fetch(pos, c);
-    __syncthreads();
+    FW_SYNC();
 #ifdef FE_PROF
     long long fp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fp_last = clock64(), fp_n = 0;
 #define FE_PROBE(k) do { const long long t_ = clock64(); fp[k] += t_ - fp_last; fp_last = t_; } while (0)
@@ -361,7 +379,7 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
         } else {
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
-                const int i = lane + 64 * it;
+                const int i = li + 64 * it;
                 if (i < c) {
                     double2 v = (okbits >> it & 1u) ? xv[it] : make_double2(0.0, 0.0);
                     if (k0 + i >= 0 && mix) { v = cmul(v, w); w = cmul(w, P64); }
@@ -376,18 +394,25 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
         const long long npos = pos + c;
         const int nc = npos < g_hi ? chunk_len(npos) : 0;
         if (nc > 0) fetch(npos, nc);
-        __syncthreads();
+        FW_SYNC();
         FE_PROBE(0);
         const long long obase = (pos >> S) - a.J0;
         const bool full = c == FW_CHUNK;                 // partial chunks (warm-up tail, span end) take the safe path
+        T cv[2];
         fw_stage<T, S, 0>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i);
-        __syncthreads();
+        FW_SYNC();
         FE_PROBE(1);
-        if (full) fw_carry(smem, 0, c >> 1, lane);
-        if constexpr (S > 1) { FE_PROBE(6); fw_stage<T, S, 1>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(2); if (full) fw_carry(smem, 1, c >> 2, lane); }
-        if constexpr (S > 2) { FE_PROBE(6); fw_stage<T, S, 2>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(3); if (full) fw_carry(smem, 2, c >> 3, lane); }
-        if constexpr (S > 3) { FE_PROBE(6); fw_stage<T, S, 3>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(4); if (full) fw_carry(smem, 3, c >> 4, lane); }
-        if constexpr (S > 4) { FE_PROBE(6); fw_stage<T, S, 4>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); __syncthreads(); FE_PROBE(5); if (full) fw_carry(smem, 4, c >> 5, lane); }
+        if (full) fw_carry_load(smem, 0, c >> 1, lane, cv);
+#define FW_NEXT(s_) \
+        if constexpr (S > s_) { \
+            fw_stage<T, S, s_>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); \
+            FW_SYNC(); \
+            FE_PROBE(s_ + 1); \
+            if (full) { fw_carry_store(smem, s_ - 1, lane, cv); fw_carry_load(smem, s_, c >> (s_ + 1), lane, cv); } \
+        }
+        FW_NEXT(1) FW_NEXT(2) FW_NEXT(3) FW_NEXT(4)
+#undef FW_NEXT
+        if (full) fw_carry_store(smem, S - 1, lane, cv);
         if (!full) {
             // generic carry with a barrier between the reads and the writes (source and destination may overlap)
             constexpr int NC = S * 4 * FE_HIST;
@@ -401,7 +426,7 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
                     keep[u] = fw_arr(smem, s, sub >> 1, sub & 1)[(c >> (s + 1)) + (sub & 1) + i];
                 }
             }
-            __syncthreads();
+            FW_SYNC();
 #pragma unroll
             for (int u = 0; u < (NC + 63) / 64; u++) {
                 const int wi = lane + 64 * u;
@@ -412,7 +437,7 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
                 }
             }
         }
-        __syncthreads();
+        FW_SYNC();
         pos = npos; c = nc;
     }
 #pragma unroll
@@ -440,6 +465,7 @@ __global__ __launch_bounds__(64) void k_frontend_wave(FrontArgs a)
 // reference's k order (a different rounding order, inside the 1e-9 contract of DESIGN.md section 3).
 // ------------------------------------------------------------------------------------------------
 #define FT_QB 8
+#define FT_LD 8
 template <int D, int NTH, int R, class T = double>
 __device__ __forceinline__ void fir_tile(const double *__restrict__ x, const T *__restrict__ hp, int TQP,
                                          int first, int jb, int t_max, T *lds, T (&acc)[R])
@@ -448,10 +474,23 @@ __device__ __forceinline__ void fir_tile(const double *__restrict__ x, const T *
     const int LEN = NO + TQP;
     const int t_lo = first + D * (jb - TQP + 1) - (D - 1);
     const int count = D * (LEN - 1);
-    for (int u = threadIdx.x; u < count; u += NTH) {
-        const int m = u / D, s = u - m * D;
-        const int t = t_lo + u;
-        lds[(D - 1 - s) * LEN + m] = t <= t_max ? (T)x[t] : T(0);
+    // FT_LD loads of a lane are in flight together (clamped index, so none is conditional): one load per trip left
+    // the kernel waiting on memory latency with a few KB in flight per CU
+    for (int u0 = threadIdx.x; u0 < count; u0 += FT_LD * NTH) {
+        double v[FT_LD];
+#pragma unroll
+        for (int i = 0; i < FT_LD; i++) {
+            const int t = t_lo + u0 + i * NTH;
+            v[i] = x[t < t_max ? t : t_max];
+        }
+#pragma unroll
+        for (int i = 0; i < FT_LD; i++) {
+            const int u = u0 + i * NTH;
+            if (u < count) {
+                const int m = u / D, s = u - m * D;
+                lds[(D - 1 - s) * LEN + m] = t_lo + u <= t_max ? (T)v[i] : T(0);
+            }
+        }
     }
     __syncthreads();
 #pragma unroll

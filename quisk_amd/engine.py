@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqkengine.so")
+LIB_PATH = os.environ.get("QK_ENGINE_LIB") or os.path.join(_HERE, "libqkengine.so")    # (QK_ENGINE_LIB: an instrumented build of the same library)
 
 
 class QkError(RuntimeError):
