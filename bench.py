@@ -203,11 +203,25 @@ def spectrum_leg(local, dev_block_ptrs, block, with_cpu):
     _, row, _ = eng.get_graph(1.0, 0.0)
     torch.cuda.synchronize()
     groups, t0 = 24, time.perf_counter()
-    for g in range(groups):             # blocks of eight frames (0.137 s of signal each), one averaged row released per block
-        eng.process_device(dev_block_ptrs[(g % 2) * 8], 8 * N)
-        _, row, _ = eng.get_graph(1.0, 0.0)
+    rows = 0
+    for g in range(groups):             # blocks of eight frames (0.137 s of signal each), one averaged row released per block:
+        eng.process_device(dev_block_ptrs[(g % 2) * 8], 8 * N)      # the row of block g is marked behind its frames and taken
+        if g:                                                       # by the host while block g + 1 is under way
+            cnt, row, _ = eng.get_graph(1.0, 0.0)
+            rows += cnt == 8
+        eng.graph_mark(1.0, 0.0)
+    cnt, row, _ = eng.get_graph(1.0, 0.0)
+    rows += cnt == 8
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if rows != groups:
+        raise SystemExit("spectrum leg: %d rows of 8 frames expected, %d released" % (groups, rows))
+    t2 = time.perf_counter()
+    for g in range(groups):             # the same with the row taken before the next block is queued (no mark)
+        eng.process_device(dev_block_ptrs[(g % 2) * 8], 8 * N)
+        eng.get_graph(1.0, 0.0)
+    torch.cuda.synchronize()
+    fps_sync = groups * 8 / (time.perf_counter() - t2)
     t1 = time.perf_counter()
     for g in range(6):                  # the same with one frame per block
         for i in range(8):
@@ -237,8 +251,8 @@ def spectrum_leg(local, dev_block_ptrs, block, with_cpu):
         except Exception:
             traffic = None
     res = {"workload": "BASELINE configs[2]: 2^20-point windowed FFT at 61.44 Msps, 8-frame magnitude average, 4096-point dB row",
-           "frames_per_s": fps, "frames_per_s_one_frame_blocks": fps_single, "realtime_frames_per_s": 61440000.0 / N,
-           "msamples_per_s": fps * N / 1e6, "block": "8 frames per qk_process_samples_device call, one row released per block",
+           "frames_per_s": fps, "frames_per_s_row_taken_before_next_block": fps_sync, "frames_per_s_one_frame_blocks": fps_single, "realtime_frames_per_s": 61440000.0 / N,
+           "msamples_per_s": fps * N / 1e6, "block": "8 frames per qk_process_samples_device call, one row released per block (qk_graph_mark behind the block, qk_get_graph while the next block runs)",
            "row_finite": bool(row is not None and np.isfinite(row).all()),
            "roofline": {"kernel": "k_fft_cols + k_fft_rows, per frame (a launch pair transforms 8 frames; HIP events on their stream)", "bound": "hbm",
                         "achieved": k_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k_gbs / HBM_PEAK_GBS,

@@ -146,6 +146,14 @@ int qk_export_audio_device(qk_engine *e, double *dst_dev, size_t dst_stride);
 int qk_get_graph(qk_engine *e, double zoom, double deltaf, double *out, int data_width, double *smeter);
 /* get_smeter (quisk.c:2737-2742): the value computed by the last qk_get_graph release. */
 double qk_get_smeter(qk_engine *e);
+/* First half of qk_get_graph, for a caller that keeps the GPU fed: queues the release of the frames averaged so far behind
+ * them (binning, dB scaling, the S-meter sum; quisk.c:4713-4753), starts a new average and returns at once with the number of
+ * frames marked (0: none waiting).  The next qk_get_graph call returns that row (its zoom / deltaf arguments are then not
+ * used) and waits for nothing queued after the mark.  One row can be marked at a time (QK_EINVAL otherwise).  The reference
+ * has the same split between its sound thread, which fills fft_data[] (quisk.c:2324-2348), and the GUI thread, which takes
+ * what is ready (quisk.c:4651-4710). */
+int qk_graph_mark(qk_engine *e, double zoom, double deltaf);
+
 /* Frames waiting in the average (count_fft, quisk.c:4613) without releasing them. */
 int qk_graph_pending(qk_engine *e);
 /* Device pointer to the last released graph row (data_width doubles), for the RCCL gather. */

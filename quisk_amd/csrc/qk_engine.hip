@@ -193,6 +193,10 @@ struct qk_engine {
     int fft_parts = 0;                     // partial averages of the four-step row pass that hold data (0 after a release)
     double *h_graph = nullptr;             // pinned staging of a released row + the S-meter sum
     long long graph_rows = 0;              // rows released so far (current_graph is all zero before the first)
+    bool rel_pending = false;              // a row marked by qk_graph_mark (or a release under way) waits to be collected
+    int rel_count = 0;                     // ... the frames in it
+    hipEvent_t ev_graph = nullptr;
+    std::vector<double> last_row;          // the row of the last release, on the host
     double k0_zoom = 0, k0_deltaf = 0; bool k0_valid = false;     // what d_k0 was made for
     double2 *d_fft_stage = nullptr, *d_fft_Y = nullptr, *d_tw4096 = nullptr, *d_tw_lo = nullptr, *d_tw_hi = nullptr;
     double *d_window = nullptr, *d_fft_avg = nullptr, *d_band = nullptr, *d_meter = nullptr, *d_graph = nullptr, *d_pix = nullptr;
@@ -1075,6 +1079,7 @@ static int init_spectrum(qk_engine *e)
     HIPCHECK(hipMalloc(&e->d_fft_avg, sizeof(double) * N * parts));
     HIPCHECK(hipMemset(e->d_fft_avg, 0, sizeof(double) * N * parts));
     HIPCHECK(hipHostMalloc(&e->h_graph, sizeof(double) * (W + 1), hipHostMallocDefault));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_graph, sync_event_flags()));
     e->band_cap = N / 2 + 2;
     HIPCHECK(hipMalloc(&e->d_band, sizeof(double) * e->band_cap * FFT_BATCH));
     HIPCHECK(hipMalloc(&e->d_meter, sizeof(double)));
@@ -1204,10 +1209,13 @@ static int feed_spectrum(qk_engine *e, const double2 *x, int n)
     return QK_OK;
 }
 
-static int release_graph(qk_engine *e, double zoom, double deltaf, double *out, int data_width, double *smeter)
+// The release is in two halves.  graph_enqueue queues the binning kernel behind the frames of the average (it writes the
+// row to the device row and to pinned host memory, and the S-meter sum behind it), starts a new average and records an event;
+// graph_collect waits for that event alone.  Frames queued in between belong to the next average and keep the GPU busy
+// while the host takes its row: stream order puts the release in front of them.
+static int graph_enqueue(qk_engine *e, double zoom, double deltaf)
 {
     const int N = e->fftN, W = e->fftW, count = e->fft_count;
-    if (data_width != W) return fail(QK_EINVAL, "data_width differs from the engine's");
     if (count <= 0) return 0;
     int n = (int)(zoom * (double)N / W + 0.5);                      // quisk.c:4715-4717
     if (n < 1) n = 1;
@@ -1227,19 +1235,27 @@ static int release_graph(qk_engine *e, double zoom, double deltaf, double *out, 
     const bool scan = e->scan_blocks > 0;
     ReleaseArgs ra{scan ? e->d_scan_avg : e->d_fft_avg, e->d_graph, e->d_k0, N, e->fftN1, W, n,
                    20.0 * (log10((double)count) + log10((double)N) + 31.0 * log10(2.0)),          // quisk.c:4741-4742
-                   (e->fftN1 > 1 && !scan) ? std::max(1, e->fft_parts) : 1, e->d_meter, scan ? 1 : 0};
+                   (e->fftN1 > 1 && !scan) ? std::max(1, e->fft_parts) : 1, e->d_meter, scan ? 1 : 0, e->h_graph};
     if (alias) hipLaunchKernelGGL(k_graph_release_inplace, dim3(1), dim3(256), 0, e->fe_stream, ra, e->d_pix);
     else hipLaunchKernelGGL(k_graph_release, dim3((W + REL_PIX - 1) / REL_PIX), dim3(64 * REL_PIX), 0, e->fe_stream, ra);
-    // one copy brings the row and the S-meter sum (the kernel left it behind the row and cleared the accumulator)
-    HIPCHECK(hipMemcpyAsync(e->h_graph, e->d_graph, sizeof(double) * (W + 1), hipMemcpyDeviceToHost, e->fe_stream));
     if (scan)
         HIPCHECK(hipMemsetAsync(e->d_scan_avg, 0, sizeof(double) * N, e->fe_stream));             // quisk.c:4750-4751
     else if (e->fftN1 <= 1)      // (the four-step pass B overwrites the average when it starts a new one: no 8 N bytes of zeros)
         HIPCHECK(hipMemsetAsync(e->d_fft_avg, 0, sizeof(double) * N, e->fe_stream));
-    HIPCHECK(hipStreamSynchronize(e->fe_stream));
-    memcpy(out, e->h_graph, sizeof(double) * W);
-    const double meter = e->h_graph[W];
+    HIPCHECK(hipEventRecord(e->ev_graph, e->fe_stream));
+    e->rel_pending = true; e->rel_count = count;
     e->fft_parts = 0;
+    e->fft_count = 0;
+    return count;
+}
+static int graph_collect(qk_engine *e, double *out, double *smeter)
+{
+    const int N = e->fftN, W = e->fftW, count = e->rel_count;
+    HIPCHECK(hipEventSynchronize(e->ev_graph));
+    e->rel_pending = false;
+    e->last_row.assign(e->h_graph, e->h_graph + W);                 // current_graph (quisk.c:4747): IsSquelch reads it
+    if (out) memcpy(out, e->h_graph, sizeof(double) * W);
+    const double meter = e->h_graph[W];
     e->graph_rows++;
     const double scale = 1.0 / 2147483647.0 / N;                    // quisk.c:4728-4737
     double sm = meter * scale * scale / count;
@@ -1247,8 +1263,16 @@ static int release_graph(qk_engine *e, double zoom, double deltaf, double *out, 
     sm += 4.25969;
     e->smeter = sm;
     if (smeter) *smeter = sm;
-    e->fft_count = 0;
     return count;
+}
+static int release_graph(qk_engine *e, double zoom, double deltaf, double *out, int data_width, double *smeter)
+{
+    if (data_width != e->fftW) return fail(QK_EINVAL, "data_width differs from the engine's");
+    if (!e->rel_pending) {
+        const int rc = graph_enqueue(e, zoom, deltaf);
+        if (rc <= 0) return rc;
+    }
+    return graph_collect(e, out, smeter);
 }
 
 // run one chain over `nlist` receivers; `input` is the stream feeding stage.in == -1
@@ -1793,6 +1817,7 @@ void qk_destroy(qk_engine *e)
                     e->d_meter, e->d_graph, e->d_pix, e->d_k0};
     for (void *p : ptrs) if (p) hipFree(p);
     if (e->h_graph) hipHostFree(e->h_graph);
+    if (e->ev_graph) hipEventDestroy(e->ev_graph);
     if (e->h_keyup) hipHostFree(e->h_keyup);
     if (e->h_keyup_counts) hipHostFree(e->h_keyup_counts);
     if (e->ev_keyup) hipEventDestroy(e->ev_keyup);
@@ -2099,6 +2124,13 @@ int qk_get_graph(qk_engine *e, double zoom, double deltaf, double *out, int data
     return release_graph(e, zoom, deltaf, out, data_width, smeter);
 }
 int qk_graph_pending(qk_engine *e) { ENGINE_ENTER(e); return e->fft_count; }
+int qk_graph_mark(qk_engine *e, double zoom, double deltaf)
+{
+    ENGINE_ENTER(e);
+    if (e->fftN <= 0) return fail(QK_EINVAL, "engine created without a display FFT");
+    if (e->rel_pending) return fail(QK_EINVAL, "a marked row has not been collected yet (qk_get_graph)");
+    return graph_enqueue(e, zoom, deltaf);
+}
 int qk_graph_device(qk_engine *e, const double **dev_ptr) { ENGINE_ENTER(e); if (dev_ptr) *dev_ptr = e->d_graph; return QK_OK; }
 double qk_get_smeter(qk_engine *e) { return e ? e->smeter : 0.0; }
 
@@ -2279,7 +2311,7 @@ int qk_is_squelch(qk_engine *e, int freq)
     const int i1 = (int)((double)freq * W / fs + W / 2.0 - bw / 2.0 + 0.5), i2 = i1 + bw;
     double meter = 0;
     if (i1 >= 0 && i2 < W && e->graph_rows > 0)
-        for (int i = i1; i < i2; i++) meter += e->h_graph[i];
+        for (int i = i1; i < i2; i++) meter += e->last_row[i];
     meter /= bw;
     return (meter == 0 || meter < e->squelch_level) ? 1 : 0;
 }
@@ -2326,6 +2358,7 @@ int qk_change_scan(qk_engine *e, int scan_blocks, int scan_sample_rate, double s
     e->scan_blocks = scan_blocks; e->scan_rate = scan_sample_rate; e->scan_valid = scan_valid; e->scan_vfo0 = scan_vfo0;
     e->scan_deltaf = scan_deltaf; e->scan_tx_tune = tx_tune_hz; e->scan_vfo_screen = vfo_screen; e->scan_next = 0;
     e->fft_count = 0; e->fft_parts = 0;
+    if (e->rel_pending) { hipEventSynchronize(e->ev_graph); e->rel_pending = false; }    // a marked row of the old setting is dropped
     return QK_OK;
 }
 
@@ -2338,7 +2371,8 @@ int qk_set_graph_raw(qk_engine *e, int on)
     HIPCHECK(hipStreamSynchronize(e->fe_stream));
     if (on && !e->d_raw_rows) HIPCHECK(hipMalloc(&e->d_raw_rows, sizeof(double2) * 4 * e->fftW));
     e->raw_mode = on; e->raw_head = e->raw_count = 0; e->fft_fill = 0;
-    e->fft_count = 0; e->fft_parts = 0;                                  // count_fft = 0, quisk.c:4618-4621
+    e->fft_count = 0; e->fft_parts = 0;
+    if (e->rel_pending) { hipEventSynchronize(e->ev_graph); e->rel_pending = false; }    // a marked row of the old setting is dropped                                  // count_fft = 0, quisk.c:4618-4621
     if (e->fftN1 <= 1) HIPCHECK(hipMemset(e->d_fft_avg, 0, sizeof(double) * e->fftN));
     HIPCHECK(hipMemset(e->d_meter, 0, sizeof(double)));
     return QK_OK;

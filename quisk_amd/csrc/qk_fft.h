@@ -456,6 +456,7 @@ struct ReleaseArgs {
     int parts;                 // partial averages to add up (four-step pass B keeps one per frame group)
     double *meter;             // S-meter accumulator: copied to out[W] and cleared (quisk.c:4728-4737 uses it on the host)
     int shifted;               // 1: avg is the stitched scan average, already in order of frequency (index = kk)
+    double *host;              // pinned host copy of the row and the meter sum, written by the kernel itself (no copy command)
 };
 __device__ __forceinline__ double avg_at(const ReleaseArgs &a, int kk)
 {
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(64 * REL_PIX) void k_graph_release(ReleaseArgs a)
 {
     const int i = blockIdx.x * REL_PIX + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { a.out[a.W] = *a.meter; *a.meter = 0.0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { const double m = *a.meter; a.out[a.W] = m; a.host[a.W] = m; *a.meter = 0.0; }
     if (i >= a.W) return;
     const int k0 = a.k0[i];
     double sum = 0.0;
@@ -500,6 +501,7 @@ __global__ __launch_bounds__(64 * REL_PIX) void k_graph_release(ReleaseArgs a)
         double d = 20.0 * log10(sum) - a.scale;
         if (d < -200) d = -200;
         a.out[i] = d;
+        a.host[i] = d;
     }
 }
 // In-place variant for the zoom settings where the reference's in-place binning reads entries it has already
@@ -524,11 +526,12 @@ __global__ __launch_bounds__(256) void k_graph_release_inplace(ReleaseArgs a, do
         if (threadIdx.x == 0) pix[i] = red[0];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { a.out[a.W] = *a.meter; *a.meter = 0.0; }
+    if (threadIdx.x == 0) { const double m = *a.meter; a.out[a.W] = m; a.host[a.W] = m; *a.meter = 0.0; }
     for (int i = threadIdx.x; i < a.W; i += 256) {
         double d = 20.0 * log10(pix[i]) - a.scale;
         if (d < -200) d = -200;
         a.out[i] = d;
+        a.host[i] = d;
     }
 }
 

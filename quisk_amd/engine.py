@@ -60,6 +60,7 @@ def lib():
     L.qk_audio_device.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.qk_get_graph.argtypes = [vp, C.c_double, C.c_double, vp, C.c_int, dp]
     L.qk_graph_pending.argtypes = [vp]
+    L.qk_graph_mark.argtypes = [vp, C.c_double, C.c_double]
     L.qk_set_ssb_squelch.argtypes = [vp, C.c_int, C.c_int]
     L.qk_set_auto_notch.argtypes = [vp, C.c_int, C.c_int]
     L.qk_set_rit_freq.argtypes = [vp, C.c_int]
@@ -292,6 +293,11 @@ class Engine:
         sm = C.c_double(0.0)
         n = _check(self.L.qk_get_graph(self.h, float(zoom), float(deltaf), out.ctypes.data, self.data_width, C.byref(sm)))
         return n, out, sm.value
+
+    def graph_mark(self, zoom=1.0, deltaf=0.0):
+        """Queue the release of the frames averaged so far and start a new average; the next get_graph returns that row
+        and waits for nothing queued after the mark.  Returns the number of frames marked."""
+        return _check(self.L.qk_graph_mark(self.h, float(zoom), float(deltaf)))
 
     def change_scan(self, scan_blocks, scan_sample_rate=0, scan_valid=0.84, scan_vfo0=0, scan_deltaf=0, tx_tune=0, vfo_screen=0):
         """change_scan (quisk.c:3865-3872): stitch the frames of a VFO sweep; scan_blocks = 0 returns to plain averaging."""

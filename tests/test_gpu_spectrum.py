@@ -134,3 +134,29 @@ def test_scan_blocks_stitching(N, W, blocks):
     eng.process(x[:2 * N]); og.add_frames(x[:2 * N])
     assert _cmp(eng, og, zoom=0.5, deltaf=1000.0) == 2
     eng.close(); og.close()
+
+
+@pytest.mark.parametrize("N,W", [(4096, 4096), (1 << 16, 1024)])
+def test_marked_release(N, W):
+    """qk_graph_mark: the row of the frames in front of the mark is released behind them and collected later, while the
+    frames behind the mark go into the next average (single-workgroup and four-step sizes; zoom with the in-place case)."""
+    fs = 192000
+    eng, og = _pair(fs, N, W)
+    x = make_iq(6 * N, fs, [20000, -50000], [3, 3], 17)
+    feed = lambda lo, hi: [eng.process(x[i:i + N]) for i in range(lo, hi, N)]
+    feed(0, 2 * N)
+    assert eng.graph_mark(0.5, 3000.0) == 2
+    assert eng.graph_pending() == 0
+    with pytest.raises(Exception):
+        eng.graph_mark(1.0, 0.0)                   # one row at a time
+    feed(2 * N, 5 * N)                             # queued behind the mark: the next average
+    assert eng.graph_pending() == 3
+    og.add_frames(x[:2 * N])
+    assert _cmp(eng, og, zoom=0.5, deltaf=3000.0) == 2      # (the arguments of the collecting call are not used)
+    og.add_frames(x[2 * N:5 * N])
+    assert _cmp(eng, og) == 3
+    assert eng.graph_mark(1.0, 0.0) == 0           # nothing waiting
+    feed(5 * N, 6 * N)
+    og.add_frames(x[5 * N:])
+    assert _cmp(eng, og) == 1
+    eng.close(); og.close()
