@@ -23,17 +23,8 @@ extern "C" void qk_phase_tables(double pre, double pim, double *C, double *B, do
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
-// Flags of the events that order one stream behind another (QK_EVENT_TIMING=1: events with time stamps, for experiments).
-static int dbg_nowait()
-{
-    static const int v = [] { const char *t = getenv("QK_DBG_NOWAIT"); return t ? atoi(t) : 0; }();
-    return v;
-}
-static unsigned sync_event_flags()
-{
-    static const int timing = [] { const char *v = getenv("QK_EVENT_TIMING"); return v ? atoi(v) : 0; }();
-    return timing ? hipEventDefault : hipEventDisableTiming;
-}
+// Flags of the events that order one stream behind another
+static unsigned sync_event_flags() { return hipEventDisableTiming; }
 #define HIPCHECK(expr)                                                                                   \
     do {                                                                                                 \
         hipError_t _e = (expr);                                                                          \
@@ -91,8 +82,9 @@ struct Chain {
     double frac_dindex = 1.0;
     int *d_frac_idx = nullptr; double *d_frac_pos = nullptr; int frac_cap = 0;
     // the positions of a block go to the device through a small ring of pinned staging buffers
+#define QK_FRAC_SLOTS 8
     struct FracSlot { int *idx = nullptr; double *pos = nullptr; hipEvent_t ev = nullptr; bool used = false; };
-    FracSlot frac_slot[4];
+    FracSlot frac_slot[QK_FRAC_SLOTS];
     int frac_next = 0;
 };
 
@@ -1380,8 +1372,8 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             const double fdecim = e->decim_srate / 48000.0;
             const double step = fdecim - 1;
             Chain::FracSlot &fs = c.frac_slot[c.frac_next];
-            c.frac_next = (c.frac_next + 1) & 3;
-            if (fs.used) HIPCHECK(hipEventSynchronize(fs.ev));       // four blocks back: only a host far ahead of the GPU waits here
+            c.frac_next = (c.frac_next + 1) % QK_FRAC_SLOTS;
+            if (fs.used) HIPCHECK(hipEventSynchronize(fs.ev));       // eight blocks back: only a host far ahead of the GPU waits here
             int n_out = 0;
             for (int i = 0; i < n_in; i++) {
                 if (c.frac_dindex < 2) {
@@ -1587,7 +1579,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     const int q = e->fe_blocks & 1;
     if (fe_writes) {
         std::swap(F.streams[0].d, F.front_alt);
-        if (e->read_pending[q] && !(dbg_nowait() & 1)) HIPCHECK(hipStreamWaitEvent(e->fe_stream, e->ev_read[q], 0));
+        if (e->read_pending[q]) HIPCHECK(hipStreamWaitEvent(e->fe_stream, e->ev_read[q], 0));
     }
     fa.out = F.streams[0].view();
     {
@@ -1659,7 +1651,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     //      block's front end and FIR chain instead of in front of them ----
     const int par = (int)(e->pipe_blocks & 1);
     HIPCHECK(hipEventRecord(e->ev_chain, e->stream));
-    if (!(dbg_nowait() & 4)) HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_chain, 0));
+    HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_chain, 0));
     if (fe_writes) {
         HIPCHECK(hipEventRecord(e->ev_read[q], e->stream));
         e->read_pending[q] = true;
@@ -1730,7 +1722,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         add_tails(ta, F, 0);        // stream 0 is carried by the head copy
         if (ta.count) hipLaunchKernelGGL(k_save_tails, dim3(ta.count, 2, e->nrx), dim3(256), 0, e->stream, ta);
         // the play streams' tails go into the twin buffers, which the previous block's AGC pass may still be reading
-        if (e->agc_pending && !(dbg_nowait() & 2)) HIPCHECK(hipStreamWaitEvent(e->stream, e->ev_agc[par ^ 1], 0));
+        if (e->agc_pending) HIPCHECK(hipStreamWaitEvent(e->stream, e->ev_agc[par ^ 1], 0));
         for (int cl = 0; cl < CL_COUNT; cl++) {
             Chain &c = e->cls_chain[cl];
             const int nl = (int)c.members.size();
