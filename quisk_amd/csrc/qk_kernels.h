@@ -1057,6 +1057,15 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                 poke(&sp_rec[slot].tag, tag_of(gen, jj) | (plain ? (int)0x80000000 : 0));
             }
         };
+#ifdef AGC_PROF
+        long long ap[4] = {0, 0, 0, 0}, ap_last = clock64(), ap_t0 = ap_last;
+        long long ac[4] = {0, 0, 0, 0};
+#define AGC_COUNT(k) ac[k]++
+#define AGC_PROBE(k) do { const long long t_ = clock64(); ap[k] += t_ - ap_last; ap_last = t_; } while (0)
+#else
+#define AGC_PROBE(k) do { } while (0)
+#define AGC_COUNT(k) do { } while (0)
+#endif
         while (alive) {
             if (j < T && j / AGC_CHUNK >= f_known) f_known = uni(peek(&fetched));   // (one look per chunk, as a rule)
             bool can = j < T && j / AGC_CHUNK < f_known;
@@ -1074,13 +1083,16 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                 while (j < jend) {
                     const int ws_v = peek(&wstat);          // (asked for before the chain, looked at after it)
                     const double mv = *mp;
+                    AGC_PROBE(0);
                     const double gs = agc_chain<true>(g0, c.keep, add, 0);
+                    AGC_PROBE(1);
                     const double pend = readlane_f64(gs, 63) * c.keep + add;
                     const double nmax = walk_max(rmax, mv, true);
                     // a restart (another generation in wstat) or the ring full: the general step deals with it
                     if ((unsigned)(j - (uni(ws_v) - (gen << 20))) >= (unsigned)AGC_RING) break;
                     hand_over(j, gs, add, pend, true, add, 0, 64);
                     g0 = pend; rmax = nmax; ++j; mp += 64;
+                    AGC_PROBE(2);
                 }
                 const bool ran_out = j >= jend;     // (not: left early for the general step)
                 ir += (j - j0) << 6;
@@ -1169,10 +1181,16 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                 waits = 0;
             } else {                                // ring full, chunk not there yet, or all tiles made: the walker may still restart
                 if (j >= T && w >= T) alive = false;
+                AGC_PROBE(0);
                 __builtin_amdgcn_s_sleep(2);
+                AGC_PROBE(3);
+                AGC_COUNT(can ? 1 : (j < T ? 2 : 3));
                 if (++waits > AGC_SPIN_LIMIT || uni(peek(&aborted))) { poke(&aborted, 1); alive = false; }
             }
         }
+#ifdef AGC_PROF
+        if (lane == 0 && rx == 0) printf("agc runner: tiles %d, cycles: pre-chain %lld chain %lld post-chain %lld waiting %lld, whole wave %lld; waits: ring full %lld, chunk not fetched %lld, all made %lld\n", T, ap[0], ap[1], ap[2], ap[3], clock64() - ap_t0, ac[1], ac[2], ac[3]);
+#endif
     } else if (wave == 1) {
         // ---------------- the walker ----------------
         int gen = 0;
