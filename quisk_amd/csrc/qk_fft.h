@@ -1,16 +1,20 @@
 // qk_fft.h -- display spectrum: window, forward complex FFT, magnitude average (get_graph, quisk.c:4602-4759;
-// window record_app quisk.c:5088-5096).  The reference calls FFTW3 (fftw_execute_dft, quisk.c:4653); this is a
-// hand-written radix-4 Stockham autosort FFT in double, staged in LDS.
+// window record_app quisk.c:5088-5096).  The reference calls FFTW3 (fftw_execute_dft, quisk.c:4653); these are
+// hand-written Stockham autosort FFTs staged in LDS, in double (or float in the engine's fp32 mode).
 //
-//   N <= 4096      one workgroup per frame: window on load, all passes in LDS, epilogue accumulates |X|.
-//   N  > 4096      four-step, N = N1 x 4096:
-//                  pass A  (k_fft_cols)  N1-point FFTs down the columns, 4096/N1 columns per workgroup (a 64 KiB
-//                          LDS tile), window on load, twiddle W_N^(n2 k1) on store, Y[k1][n2] to HBM;
-//                  pass B  (k_fft_rows)  4096-point FFT of each row Y[k1][.], epilogue accumulates |X[k1 + N1 k2]|
-//                          into the average, kept in the same [k1][k2] layout so every HBM access is contiguous.
-//                          The release kernel undoes the layout (and the fftshift) when it bins pixels.
-// Algorithmic HBM bytes per frame: read 16 N (samples); the four-step adds 32 N for Y and 16 N for the
-// read-modify-write of the average.
+//   N <= 4096      one workgroup per frame (k_fft_small, radix-4 passes of lds_fft): window on load, all passes in
+//                  LDS, epilogue accumulates |X|.  lds_fft also serves the audio-rate kernels at the end of this file.
+//   N  > 4096      four-step, N = N1 x 4096, eight frames per launch pair, compile-time radix-16 passes (ft_pass16,
+//                  ft_final, ft_run: 16 points per lane in registers, twiddles from four table entries and products):
+//                  pass A  (k_fft_cols)  N1-point FFTs down the columns, window on load (one table product per lane
+//                          times compile-time W16^j), twiddle W_N^(n2 k1) on store, Y[frame][k1][n2] to HBM;
+//                  pass B  (k_fft_rows)  4096-point FFT of each row Y[k1][.] in three LDS exchanges; a workgroup walks
+//                          the frames of its group with the next frame's row prefetched in registers, accumulates
+//                          |X[k1 + N1 k2]| in registers and writes ONE partial average per group and launch, in the
+//                          same [k1][k2] layout so every HBM access is contiguous.  The release kernel adds the
+//                          parts and undoes the layout (and the fftshift) when it bins pixels.
+// Algorithmic HBM bytes per frame: read 16 N (samples); the four-step adds 32 N for Y and 2 N for the partial
+// averages (measured 56 MB per 2^20-point frame with tables and the release, profiles/r02_pmc_fft.json).
 #pragma once
 #include <hip/hip_runtime.h>
 
