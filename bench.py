@@ -374,27 +374,14 @@ def main():
             assert audio.shape[0] == n_local * world and int(cnt.min().item()) > 0
         return {"ms": ms, "bytes": int(n_local * world * stride * 16), "receivers": n_local * world}
 
-    dt, st = timed_leg(eng, ptrs, block, a.steps, a.warmup, barrier, (KT_FRONTEND,))
-    dt = max_over_ranks(dt, torch.device("cuda", local))
-    gather = gather_outputs(eng, nrx) if world > 1 else None
-
-    value = a.steps * block * world / dt / 1e6
-    step_ms = dt / a.steps * 1e3
-    res = {
-        "metric": "input Msamples/s processed (whole node) at %d receivers per GPU" % nrx,
-        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if a.fp32 else "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: %d %s receivers per GPU on a %.3f Msps complex-double stream, "
-                               "mixer + cascaded decimating FIRs + demod + AGC" % (nrx, "SSB" if a.mix == "ssb" else "mixed SSB/AM/FM", fs / 1e6),
-                   "block_samples": block, "receivers_total": total_rx, "sample_rate": fs, "sharding": "receivers"},
-        "realtime_factor": value * 1e6 / world / fs,
-        "receiver_msamples_per_s": value * nrx,
-        "roofline": frontend_roofline(st, fs, block, nrx, step_ms, a.fp32, "r02_pmc_frontend_c2.json"),
-    }
-    if gather is not None:
-        res["gather"] = gather
-    eng.close()
+    # The headline leg runs twice: once straight after set-up, when the GPU has been idle (its clocks take some 20 ms of
+    # load to come up: a 20-step timed region lies wholly inside that ramp), and again -- the figure reported as `value` --
+    # after the C4 / C5 legs have kept the GPU busy, i.e. at the clocks a receiver that runs for more than a few
+    # milliseconds sees.  Both are W warm-up steps followed by exactly K timed steps between barriers.
+    dt_idle, _ = timed_leg(eng, ptrs, block, a.steps, a.warmup, barrier, (KT_FRONTEND,))
+    dt_idle = max_over_ranks(dt_idle, torch.device("cuda", local))
+    res = {}
+    later = []
 
     # ---- the north-star slice: configs[3] per GPU ----
     if not a.no_config4 and block >= (1 << 20):
@@ -414,7 +401,7 @@ def main():
                "roofline": frontend_roofline(st4, fs4, block, nrx4, dt4 / k4 * 1e3, a.fp32, "r02_pmc_frontend_c4.json")}
         if world > 1:
             leg["gather"] = gather_outputs(eng4, nrx4)
-        eng4.close()
+        later.append(eng4)       # (closed behind the headline leg: freeing its buffers would idle the GPU in front of it)
         res["config4_slice"] = leg
 
     # ---- configs[4] per GPU: the same slice in the engine's fp32 mode with the 2^20-point display FFT running beside it ----
@@ -439,7 +426,35 @@ def main():
             "tolerance": "tests/test_gpu_fp32.py: audio in front of the AGC <= 1e-5 relative RMS (floor 1e-8 of the stream's peak), "
                          "spectrum <= 0.01 dB, against the fp64 oracle",
             "roofline": frontend_roofline(st5, fs5, block, nrx5, dt5 / k5 * 1e3, True, "r02_pmc_frontend_c5.json")}
-        eng5.close()
+        later.append(eng5)
+
+    dt, st = timed_leg(eng, ptrs, block, a.steps, a.warmup, barrier, (KT_FRONTEND,))
+    dt = max_over_ranks(dt, torch.device("cuda", local))
+    gather = gather_outputs(eng, nrx) if world > 1 else None
+
+    value = a.steps * block * world / dt / 1e6
+    step_ms = dt / a.steps * 1e3
+    res0 = res
+    res = {
+        "metric": "input Msamples/s processed (whole node) at %d receivers per GPU" % nrx,
+        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if a.fp32 else "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: %d %s receivers per GPU on a %.3f Msps complex-double stream, "
+                               "mixer + cascaded decimating FIRs + demod + AGC" % (nrx, "SSB" if a.mix == "ssb" else "mixed SSB/AM/FM", fs / 1e6),
+                   "block_samples": block, "receivers_total": total_rx, "sample_rate": fs, "sharding": "receivers"},
+        "realtime_factor": value * 1e6 / world / fs,
+        "receiver_msamples_per_s": value * nrx,
+        "roofline": frontend_roofline(st, fs, block, nrx, step_ms, a.fp32, "r02_pmc_frontend_c2.json"),
+    }
+    res["after_idle"] = {"ms_per_step": dt_idle / a.steps * 1e3, "value": a.steps * block * world / dt_idle / 1e6,
+                         "note": "the same leg run first, straight after set-up: the GPU's clocks are still coming up from idle"}
+    res.update(res0)
+    if gather is not None:
+        res["gather"] = gather
+    eng.close()
+    for e_ in later:
+        e_.close()
 
     with_cpu = rank == 0 and not a.no_cpu_baseline and world == 1
     if rank == 0 and not a.no_spectrum:
