@@ -112,6 +112,7 @@ struct qk_engine {
     //                  pass is the pipeline's critical loop, and the 17 us of the apply pass do not belong in it
     hipStream_t apply_stream = nullptr; bool last_apply_own = false; hipEvent_t ev_gain = nullptr; double *d_gains2 = nullptr; int *d_agc_started2 = nullptr;
     hipEvent_t ev_chain = nullptr, ev_agc[2] = {nullptr, nullptr};
+    hipEvent_t ev_front = nullptr, ev_lane[2] = {nullptr, nullptr};      // fork / join of the second lane of class chains
     hipEvent_t ev_fe = nullptr, ev_fe2 = nullptr;      // front end (and head copy) of this block done (alternating)
     hipEvent_t ev_read[2] = {nullptr, nullptr};        // the chains have finished reading front-stream twin q
     bool read_pending[2] = {false, false};
@@ -123,6 +124,7 @@ struct qk_engine {
     bool fp32 = false;         // qk_config.reserved[1]: the front end, the tiled FIRs and the display FFT compute in float
     float *d_coefs_f = nullptr, *d_taps_f = nullptr;
     int fe_rate = 0, decim_srate = 0;
+    int last_m_max = 0;        // audio samples per receiver of the previous block (0: none yet)
     int fe_slots = 2304;       // resident one-wave workgroups of k_frontend_wave on the whole chip (occupancy query)
     int fe_share = 100;        // percent of the resident slots the front end may occupy (QK_FE_SHARE)
     int fe_rounds = 2;         // front-end workgroups launched per resident slot (QK_FE_ROUNDS)
@@ -787,6 +789,9 @@ static int engine_init(qk_engine *e)
     HIPCHECK(hipEventCreateWithFlags(&e->ev_read[0], sync_event_flags()));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_read[1], sync_event_flags()));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_chain, sync_event_flags()));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_front, sync_event_flags()));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_lane[0], sync_event_flags()));
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_lane[1], sync_event_flags()));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_agc[0], sync_event_flags()));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_agc[1], sync_event_flags()));
     e->nrx = cfg.n_receivers;
@@ -1268,7 +1273,7 @@ static int release_graph(qk_engine *e, double zoom, double deltaf, double *out, 
 }
 
 // run one chain over `nlist` receivers; `input` is the stream feeding stage.in == -1
-static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_list, int nlist)
+static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_list, int nlist, hipStream_t cs)
 {
     for (auto &st : c.stages) {
         const Stream &in = st.in < 0 ? input : c.streams[st.in];
@@ -1283,11 +1288,11 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             if (n_out > 0) {
                 const bool f32 = e->fp32 && st.hf;
                 FirTArgs a{in.view(), out.view(), f32 ? (const void *)st.hf : (const void *)st.h, st.TQP, first, n_out, d_list};
-                Timer tm(e, st.timer);
+                Timer tm(e, st.timer, cs);
                 const dim3 grid((n_out + FT_NTH * FT_R - 1) / (FT_NTH * FT_R), in.planes, nlist);
                 const size_t lds = (f32 ? sizeof(float) : sizeof(double)) * st.D * (FT_NTH * FT_R + st.TQP);
-#define QK_FIR(DD) case DD: if (f32) hipLaunchKernelGGL((k_fir_tiled<DD, FT_NTH, FT_R, float>), grid, dim3(FT_NTH), lds, e->stream, a); \
-                            else hipLaunchKernelGGL((k_fir_tiled<DD, FT_NTH, FT_R, double>), grid, dim3(FT_NTH), lds, e->stream, a); break
+#define QK_FIR(DD) case DD: if (f32) hipLaunchKernelGGL((k_fir_tiled<DD, FT_NTH, FT_R, float>), grid, dim3(FT_NTH), lds, cs, a); \
+                            else hipLaunchKernelGGL((k_fir_tiled<DD, FT_NTH, FT_R, double>), grid, dim3(FT_NTH), lds, cs, a); break
                 switch (st.D) {
                 QK_FIR(1); QK_FIR(2); QK_FIR(3); QK_FIR(5);
                 default: return fail(QK_EINVAL, "internal: FIR decimation factor without a kernel");
@@ -1300,8 +1305,8 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             out.n = n_in * st.L;
             if (out.n > 0) {
                 InterpArgs a{in.view(), out.view(), st.h, st.T, st.L, n_in, d_list, (st.delayed && e->ssb_sq_enabled) ? SSQ_N : 0};
-                Timer tm(e, st.timer);
-                hipLaunchKernelGGL(k_interp, grid1(out.n, 1, nlist), dim3(256), 0, e->stream, a);
+                Timer tm(e, st.timer, cs);
+                hipLaunchKernelGGL(k_interp, grid1(out.n, 1, nlist), dim3(256), 0, cs, a);
             }
             break;
         }
@@ -1309,8 +1314,8 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             out.n = n_in * 2;
             if (n_in > 0) {
                 HbInterpArgs a{in.view(), out.view(), n_in, d_list, (st.delayed && e->ssb_sq_enabled) ? SSQ_N : 0};
-                Timer tm(e, st.timer);
-                hipLaunchKernelGGL(k_hb_interp, grid1(n_in, in.planes, nlist), dim3(256), 0, e->stream, a);
+                Timer tm(e, st.timer, cs);
+                hipLaunchKernelGGL(k_hb_interp, grid1(n_in, in.planes, nlist), dim3(256), 0, cs, a);
             }
             break;
         }
@@ -1322,8 +1327,8 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             out.n = n_out;
             if (n_out > 0) {
                 ResampArgs a{in.view(), out.view(), st.h, st.T, st.L, st.D, idx0, n_out, d_list};
-                Timer tm(e, st.timer);
-                hipLaunchKernelGGL(k_resample, grid1(n_out, 2, nlist), dim3(256), 0, e->stream, a);
+                Timer tm(e, st.timer, cs);
+                hipLaunchKernelGGL(k_resample, grid1(n_out, 2, nlist), dim3(256), 0, cs, a);
             }
             break;
         }
@@ -1332,13 +1337,13 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             if (n_in > 0) {
                 RxfArgs a{in.view(), out.view(), e->fp32 ? (const void *)e->d_taps_f : (const void *)e->d_taps, e->d_ntaps, e->d_mode, e->tap_cap, n_in,
                           st.rxf_kind, d_list};
-                Timer tm(e, st.timer);
+                Timer tm(e, st.timer, cs);
                 int nmax = 0;
                 for (int r : c.members) nmax = std::max(nmax, e->ntaps[r]);
                 const int tqp = std::max(FT_QB, (nmax + FT_QB - 1) / FT_QB * FT_QB);
                 const dim3 grid((n_in + FT_NTH * FT_R - 1) / (FT_NTH * FT_R), 1, nlist);
-                if (e->fp32) hipLaunchKernelGGL((k_rxf_tiled<FT_NTH, FT_R, float>), grid, dim3(FT_NTH), sizeof(float) * (FT_NTH * FT_R + tqp), e->stream, a);
-                else hipLaunchKernelGGL((k_rxf_tiled<FT_NTH, FT_R, double>), grid, dim3(FT_NTH), sizeof(double) * (FT_NTH * FT_R + tqp), e->stream, a);
+                if (e->fp32) hipLaunchKernelGGL((k_rxf_tiled<FT_NTH, FT_R, float>), grid, dim3(FT_NTH), sizeof(float) * (FT_NTH * FT_R + tqp), cs, a);
+                else hipLaunchKernelGGL((k_rxf_tiled<FT_NTH, FT_R, double>), grid, dim3(FT_NTH), sizeof(double) * (FT_NTH * FT_R + tqp), cs, a);
             }
             break;
         }
@@ -1347,12 +1352,12 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             if (n_in > 0) {
                 const int np = (n_in + 255) / 256;      // = grid1's x extent
                 FmDiscArgs a{in.view(), out.view(), n_in, st.fs, d_list, e->d_sq_partial, e->sq_pstride};
-                Timer tm(e, st.timer);
-                hipLaunchKernelGGL(k_fm_disc, grid1(n_in, 1, nlist), dim3(256), 0, e->stream, a);
+                Timer tm(e, st.timer, cs);
+                hipLaunchKernelGGL(k_fm_disc, grid1(n_in, 1, nlist), dim3(256), 0, cs, a);
                 // the FM squelch measures the filtered samples (quisk.c:1892, 1911-1920)
                 SquelchArgs q{e->d_sq_partial, e->sq_pstride, np, n_in, d_list, e->d_sq_state, e->d_sq_flag + (e->pipe_blocks & 1) * e->nrx,
                               e->squelch_level};
-                hipLaunchKernelGGL(k_fm_squelch, dim3(nlist), dim3(256), 0, e->stream, q);
+                hipLaunchKernelGGL(k_fm_squelch, dim3(nlist), dim3(256), 0, cs, q);
             }
             break;
         }
@@ -1360,8 +1365,8 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             out.n = n_in;
             if (n_in > 0) {
                 IirArgs a{in.view(), out.view(), n_in, st.iir_kind, st.a0, st.a1, st.b1, st.iir_state, d_list, nlist};
-                Timer tm(e, st.timer);
-                hipLaunchKernelGGL(k_serial_iir, dim3(nlist), dim3(64), 0, e->stream, a);
+                Timer tm(e, st.timer, cs);
+                hipLaunchKernelGGL(k_serial_iir, dim3(nlist), dim3(64), 0, cs, a);
             }
             break;
         }
@@ -1384,15 +1389,15 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             }
             out.n = n_out;
             if (n_out > 0) {
-                hipLaunchKernelGGL(k_stage_frac, dim3((n_out + 255) / 256), dim3(256), 0, e->stream, fs.idx, fs.pos,
+                hipLaunchKernelGGL(k_stage_frac, dim3((n_out + 255) / 256), dim3(256), 0, cs, fs.idx, fs.pos,
                                    c.d_frac_idx, c.d_frac_pos, n_out);
-                HIPCHECK(hipEventRecord(fs.ev, e->stream));
+                HIPCHECK(hipEventRecord(fs.ev, cs));
                 fs.used = true;
             }
             if (n_out > 0) {
                 FracArgs a{in.view(), out.view(), c.d_frac_idx, c.d_frac_pos, n_out, d_list};
-                Timer tm(e, st.timer);
-                hipLaunchKernelGGL(k_fracdecim, grid1(n_out, out.planes, nlist), dim3(256), 0, e->stream, a);
+                Timer tm(e, st.timer, cs);
+                hipLaunchKernelGGL(k_fracdecim, grid1(n_out, out.planes, nlist), dim3(256), 0, cs, a);
             }
             break;
         }
@@ -1402,12 +1407,12 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             const bool cw = &c == &e->cls_chain[CL_CW];
             if (e->any_notch) {
                 NotchArgs na{out.view(), out.n, rate, cw ? e->rit_freq : 0, d_list, e->d_notch_on, e->d_mode, e->d_notch, e->d_tw4096};
-                hipLaunchKernelGGL(k_auto_notch, dim3(nlist), dim3(256), 0, e->stream, na);
+                hipLaunchKernelGGL(k_auto_notch, dim3(nlist), dim3(256), 0, cs, na);
             }
             if (st.hook == 1 && e->ssb_sq_enabled) {
                 SsbSquelchArgs sa{out.view(), out.n, rate, e->ssb_sq_level, d_list, e->d_bw, e->d_ssb_carry, e->d_ssb_state,
                                   e->d_sq_flag + (e->pipe_blocks & 1) * e->nrx, e->d_tw4096};
-                hipLaunchKernelGGL(k_ssb_squelch, dim3(nlist), dim3(256), 0, e->stream, sa);
+                hipLaunchKernelGGL(k_ssb_squelch, dim3(nlist), dim3(256), 0, cs, sa);
             }
         }
     }
@@ -1629,10 +1634,34 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         HIPCHECK(hipStreamWaitEvent(e->stream, evf, 0));
     }
     // ---- remaining integer decimation, all receivers ----
-    int rc = run_chain(e, F, F.streams[0], nullptr, e->nrx);
+    int rc = run_chain(e, F, F.streams[0], nullptr, e->nrx, e->stream);
     if (rc != QK_OK) return rc;
     const Stream &dec = F.streams[F.aud];
-    // ---- per class: demodulate and audio chain on the main stream ----
+    // ---- per class: demodulate and audio chain.  The classes are independent of each other and each is a string of a
+    //      dozen short, launch-latency-bound kernels: with more than one class present they go down two lanes, the main
+    //      stream and the apply stream (idle at this point of the block, and a stream of its own would share a hardware
+    //      queue with one of the four), so that the strings run side by side. ----
+    int lane_of[CL_COUNT] = {0};
+    hipStream_t lanes[3] = {e->stream, e->apply_stream, e->agc_stream};
+    // (the AGC's stream serves as a third lane where the AGC's own pass is short: few audio samples per block)
+    const int n_lanes = !e->apply_stream ? 1 : (e->last_m_max > 0 && e->last_m_max < 2048 ? 3 : 2);
+    bool lane_used[3] = {true, false, false};
+    {
+        int load[3] = {0, 0, 0};
+        for (int cl = 0; cl < CL_COUNT; cl++) {
+            const Chain &c = e->cls_chain[cl];
+            if (c.members.empty()) continue;
+            int l = 0;
+            for (int k = 1; k < n_lanes; k++) if (load[k] < load[l]) l = k;
+            lane_of[cl] = l;
+            load[l] += (int)c.stages.size();
+            lane_used[l] = true;
+        }
+    }
+    if (lane_used[1] || lane_used[2]) {
+        HIPCHECK(hipEventRecord(e->ev_front, e->stream));
+        for (int k = 1; k < 3; k++) if (lane_used[k]) HIPCHECK(hipStreamWaitEvent(lanes[k], e->ev_front, 0));
+    }
     for (int cl = 0; cl < CL_COUNT; cl++) {
         Chain &c = e->cls_chain[cl];
         const int nl = (int)c.members.size();
@@ -1640,7 +1669,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         // the play-rate stream is double-buffered: this block writes the twin whose history the previous block's
         // tail copy prepared, while the AGC pass of the previous block may still read the other one
         std::swap(c.streams[c.play].d, c.play_alt);
-        rc = run_chain(e, c, dec, c.d_members, nl);
+        rc = run_chain(e, c, dec, c.d_members, nl, lanes[lane_of[cl]]);
         if (rc != QK_OK) return rc;
         c.n_out = c.streams[c.play].n;
         if (c.n_out == 0) std::swap(c.streams[c.play].d, c.play_alt);     // nothing written: stay on the same twin
@@ -1650,6 +1679,13 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     // ---- AGC on its own stream: serial in time per receiver (one wave each), so it runs beside the next
     //      block's front end and FIR chain instead of in front of them ----
     const int par = (int)(e->pipe_blocks & 1);
+    for (int k = 1; k < 3; k++) {
+        // the other lanes join: the AGC, the tail copies and the next block's decimators (which overwrite what these
+        // chains read) all come behind them
+        if (!lane_used[k]) continue;
+        HIPCHECK(hipEventRecord(e->ev_lane[k - 1], lanes[k]));
+        HIPCHECK(hipStreamWaitEvent(e->stream, e->ev_lane[k - 1], 0));
+    }
     HIPCHECK(hipEventRecord(e->ev_chain, e->stream));
     HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_chain, 0));
     if (fe_writes) {
@@ -1674,6 +1710,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             if (a.cpx_c[cl]) { a.mag_c[cl] = StreamView{e->d_agc_mag, e->gain_stride, e->gain_stride, 0}; any_cpx = any_cpx || on; }
             m_max = std::max(m_max, a.n_c[cl]);
         }
+        e->last_m_max = m_max;
         if (m_max > 0) {
             a.cls = e->d_cls; a.gains = (e->apply_stream && par) ? e->d_gains2 : e->d_gains; a.gain_stride = e->gain_stride;
             a.buf_size = rate * 15 / 1000; a.n_rx = e->nrx;
@@ -1825,6 +1862,8 @@ void qk_destroy(qk_engine *e)
     if (e->d_agc_started2) hipFree(e->d_agc_started2);
     if (e->h_agc_abort) hipHostFree(e->h_agc_abort);
     if (e->ev_chain) hipEventDestroy(e->ev_chain);
+    if (e->ev_front) hipEventDestroy(e->ev_front);
+    for (auto &ev : e->ev_lane) if (ev) hipEventDestroy(ev);
     for (auto &ev : e->ev_agc) if (ev) hipEventDestroy(ev);
     if (e->ev_fe) hipEventDestroy(e->ev_fe);
     if (e->ev_fe2) hipEventDestroy(e->ev_fe2);
