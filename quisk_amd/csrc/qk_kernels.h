@@ -154,6 +154,9 @@ __global__ __launch_bounds__(256) void k_mixhist_update(FrontArgs a, double2 *hi
 // a busy one.
 // ------------------------------------------------------------------------------------------------
 #define FW_CHUNK 384
+#ifndef FE_SKIP
+#define FE_SKIP 0     // instrumented builds: bit 0 no mixer stores, 1..5 no stage 0..4, 6 no carries (outputs wrong, counters matter)
+#endif
 #ifndef FE_WAVES_PER_EU
 #define FE_WAVES_PER_EU 2
 #endif
@@ -184,6 +187,41 @@ __device__ __forceinline__ void hb45_out(const T *__restrict__ O, const T *__res
         const V2 *pe = reinterpret_cast<const V2 *>(__builtin_assume_aligned(E, sizeof(V2))) + (m0 / 2 + 6);
 #pragma unroll
         for (int j = 0; j < R / 2; j++) { const V2 v = pe[j]; e[2 * j] = v.x; e[2 * j + 1] = v.y; }
+    } else if constexpr (sizeof(T) == 8 && R == 3) {
+        // 24 + 3 single ds_read_b64: the compiler pairs neighbouring 8-byte reads into ds_read2_b64, which the LDS serves at
+        // half the rate of ds_read_b64 (8 clk per 16 B against 2 clk per 8 B), so the loads are spelled out.  The low 32
+        // bits of a generic pointer into LDS are the LDS byte address.
+        const unsigned ao = (unsigned)reinterpret_cast<size_t>(O + m0 + 2), ae = (unsigned)reinterpret_cast<size_t>(E + m0 + 12);
+        asm volatile(
+            "ds_read_b64 %0, %27\n\tds_read_b64 %1, %27 offset:8\n\tds_read_b64 %2, %27 offset:16\n\tds_read_b64 %3, %27 offset:24\n\t"
+            "ds_read_b64 %4, %27 offset:32\n\tds_read_b64 %5, %27 offset:40\n\tds_read_b64 %6, %27 offset:48\n\tds_read_b64 %7, %27 offset:56\n\t"
+            "ds_read_b64 %8, %27 offset:64\n\tds_read_b64 %9, %27 offset:72\n\tds_read_b64 %10, %27 offset:80\n\tds_read_b64 %11, %27 offset:88\n\t"
+            "ds_read_b64 %12, %27 offset:96\n\tds_read_b64 %13, %27 offset:104\n\tds_read_b64 %14, %27 offset:112\n\tds_read_b64 %15, %27 offset:120\n\t"
+            "ds_read_b64 %16, %27 offset:128\n\tds_read_b64 %17, %27 offset:136\n\tds_read_b64 %18, %27 offset:144\n\tds_read_b64 %19, %27 offset:152\n\t"
+            "ds_read_b64 %20, %27 offset:160\n\tds_read_b64 %21, %27 offset:168\n\tds_read_b64 %22, %27 offset:176\n\tds_read_b64 %23, %27 offset:184\n\t"
+            "ds_read_b64 %24, %28\n\tds_read_b64 %25, %28 offset:8\n\tds_read_b64 %26, %28 offset:16\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]),
+              "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]), "=&v"(o[16]), "=&v"(o[17]), "=&v"(o[18]),
+              "=&v"(o[19]), "=&v"(o[20]), "=&v"(o[21]), "=&v"(o[22]), "=&v"(o[23]), "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2])
+            : "v"(ao), "v"(ae)
+            : "memory");
+    } else if constexpr (sizeof(T) == 8 && R == 1) {
+        const unsigned ao = (unsigned)reinterpret_cast<size_t>(O + m0 + 2), ae = (unsigned)reinterpret_cast<size_t>(E + m0 + 12);
+        asm volatile(
+            "ds_read_b64 %0, %23\n\tds_read_b64 %1, %23 offset:8\n\tds_read_b64 %2, %23 offset:16\n\tds_read_b64 %3, %23 offset:24\n\t"
+            "ds_read_b64 %4, %23 offset:32\n\tds_read_b64 %5, %23 offset:40\n\tds_read_b64 %6, %23 offset:48\n\tds_read_b64 %7, %23 offset:56\n\t"
+            "ds_read_b64 %8, %23 offset:64\n\tds_read_b64 %9, %23 offset:72\n\tds_read_b64 %10, %23 offset:80\n\tds_read_b64 %11, %23 offset:88\n\t"
+            "ds_read_b64 %12, %23 offset:96\n\tds_read_b64 %13, %23 offset:104\n\tds_read_b64 %14, %23 offset:112\n\tds_read_b64 %15, %23 offset:120\n\t"
+            "ds_read_b64 %16, %23 offset:128\n\tds_read_b64 %17, %23 offset:136\n\tds_read_b64 %18, %23 offset:144\n\tds_read_b64 %19, %23 offset:152\n\t"
+            "ds_read_b64 %20, %23 offset:160\n\tds_read_b64 %21, %23 offset:168\n\t"
+            "ds_read_b64 %22, %24\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]),
+              "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]), "=&v"(o[16]), "=&v"(o[17]), "=&v"(o[18]),
+              "=&v"(o[19]), "=&v"(o[20]), "=&v"(o[21]), "=&v"(e[0])
+            : "v"(ao), "v"(ae)
+            : "memory");
     } else {
 #pragma unroll
         for (int j = 0; j < R + 21; j++) o[j] = O[m0 + 2 + j];
@@ -218,11 +256,17 @@ __device__ __forceinline__ void fw_carry_load(const T *smem, int s, int n_new, i
     const int l = lane < 44 ? lane : 43;
     const int sub = l / 11, i = (l % 11) * 2;               // 4 sub-arrays x 11 pairs
     const T *arr = smem + FwLayout::level_off(s) + sub * FwLayout::sub(s) + (sub & 1);
-    v[0] = arr[n_new + i]; v[1] = arr[n_new + i + 1];
+    if constexpr (sizeof(T) == 8) {     // (two single reads, not the ds_read2_b64 the compiler would make of them: see hb45_out)
+        const unsigned ad = (unsigned)reinterpret_cast<size_t>(arr + n_new + i);
+        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad) : "memory");
+    } else {
+        v[0] = arr[n_new + i]; v[1] = arr[n_new + i + 1];
+    }
 }
 template <class T>
 __device__ __forceinline__ void fw_carry_store(T *smem, int s, int lane, const T (&v)[2])
 {
+    if constexpr (sizeof(T) == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the compiler does not count the spelled-out reads)
     if (lane < 44) {
         const int sub = lane / 11, i = (lane % 11) * 2;
         T *arr = smem + FwLayout::level_off(s) + sub * FwLayout::sub(s) + (sub & 1);
@@ -374,7 +418,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FE_WAVES_PER
             for (int it = 0; it < NIT; it++) {
                 const double2 v = cmul(xv[it], w);
                 w = cmul(w, P64);
-                d0[dofs + 32 * it] = (T)v.x; d1[dofs + 32 * it] = (T)v.y;
+                if (!(FE_SKIP & 1)) { d0[dofs + 32 * it] = (T)v.x; d1[dofs + 32 * it] = (T)v.y; } else { pend_y[0] += (T)(v.x + v.y); }
             }
         } else {
 #pragma unroll
@@ -399,20 +443,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FE_WAVES_PER
         const long long obase = (pos >> S) - a.J0;
         const bool full = c == FW_CHUNK;                 // partial chunks (warm-up tail, span end) take the safe path
         T cv[2];
-        fw_stage<T, S, 0>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i);
+        if (!(FE_SKIP & 2)) fw_stage<T, S, 0>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i);
         FW_SYNC();
         FE_PROBE(1);
-        if (full) fw_carry_load(smem, 0, c >> 1, lane, cv);
+        if (full && !(FE_SKIP & 64)) fw_carry_load(smem, 0, c >> 1, lane, cv);
 #define FW_NEXT(s_) \
         if constexpr (S > s_) { \
-            fw_stage<T, S, s_>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); \
+            if (!(FE_SKIP & (2 << s_))) fw_stage<T, S, s_>(smem, c, lane, emit, out0, out1, obase, dummy, pend_y, pend_i); \
             FW_SYNC(); \
             FE_PROBE(s_ + 1); \
-            if (full) { fw_carry_store(smem, s_ - 1, lane, cv); fw_carry_load(smem, s_, c >> (s_ + 1), lane, cv); } \
+            if (full && !(FE_SKIP & 64)) { fw_carry_store(smem, s_ - 1, lane, cv); fw_carry_load(smem, s_, c >> (s_ + 1), lane, cv); } \
         }
         FW_NEXT(1) FW_NEXT(2) FW_NEXT(3) FW_NEXT(4)
 #undef FW_NEXT
-        if (full) fw_carry_store(smem, S - 1, lane, cv);
+        if (full && !(FE_SKIP & 64)) fw_carry_store(smem, S - 1, lane, cv);
         if (!full) {
             // generic carry with a barrier between the reads and the writes (source and destination may overlap)
             constexpr int NC = S * 4 * FE_HIST;
