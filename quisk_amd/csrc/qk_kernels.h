@@ -173,14 +173,32 @@ __device__ __forceinline__ T *fw_arr(T *smem, int s, int plane, int phase)
     return smem + FwLayout::level_off(s) + (plane * 2 + phase) * FwLayout::sub(s);
 }
 
-template <class T, int R>
+template <class T, int R, bool LAST = false>
 __device__ __forceinline__ void hb45_out(const T *__restrict__ O, const T *__restrict__ E, int m0, T (&y)[R])
 {
     // o[j] = O[m0 + 2 + j] (odd-phase samples m0-21 .. m0+R-1), e[r] = E[m0 + 12 + r] (even-phase sample m0+r-10)
     typedef typename QkVec2<T>::type V2;
     T o[R + 22];
     T e[R + 1];
-    if constexpr (R % 2 == 0) {         // m0 even: two-element vector reads (16 bytes in double, 8 in float)
+    if constexpr (sizeof(T) == 8 && R == 2 && LAST) {
+        // (23 + 2 single reads: measured faster than the 13 ds_read_b128 of the vector form where this is the last level and
+        // all 64 lanes read -- 398 against 405 us at S = 3 -- and slower where it is not: 248 against 233 us at S = 4)
+        const unsigned ao = (unsigned)reinterpret_cast<size_t>(O + m0 + 2), ae = (unsigned)reinterpret_cast<size_t>(E + m0 + 12);
+        asm volatile(
+            "ds_read_b64 %0, %25\n\tds_read_b64 %1, %25 offset:8\n\tds_read_b64 %2, %25 offset:16\n\tds_read_b64 %3, %25 offset:24\n\t"
+            "ds_read_b64 %4, %25 offset:32\n\tds_read_b64 %5, %25 offset:40\n\tds_read_b64 %6, %25 offset:48\n\tds_read_b64 %7, %25 offset:56\n\t"
+            "ds_read_b64 %8, %25 offset:64\n\tds_read_b64 %9, %25 offset:72\n\tds_read_b64 %10, %25 offset:80\n\tds_read_b64 %11, %25 offset:88\n\t"
+            "ds_read_b64 %12, %25 offset:96\n\tds_read_b64 %13, %25 offset:104\n\tds_read_b64 %14, %25 offset:112\n\tds_read_b64 %15, %25 offset:120\n\t"
+            "ds_read_b64 %16, %25 offset:128\n\tds_read_b64 %17, %25 offset:136\n\tds_read_b64 %18, %25 offset:144\n\tds_read_b64 %19, %25 offset:152\n\t"
+            "ds_read_b64 %20, %25 offset:160\n\tds_read_b64 %21, %25 offset:168\n\tds_read_b64 %22, %25 offset:176\n\t"
+            "ds_read_b64 %23, %26\n\tds_read_b64 %24, %26 offset:8\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]),
+              "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]), "=&v"(o[16]), "=&v"(o[17]), "=&v"(o[18]),
+              "=&v"(o[19]), "=&v"(o[20]), "=&v"(o[21]), "=&v"(o[22]), "=&v"(e[0]), "=&v"(e[1])
+            : "v"(ao), "v"(ae)
+            : "memory");
+    } else if constexpr (R % 2 == 0) {         // m0 even: two-element vector reads (16 bytes in double, 8 in float)
         const V2 *po = reinterpret_cast<const V2 *>(__builtin_assume_aligned(O, sizeof(V2))) + (m0 / 2 + 1);
 #pragma unroll
         for (int j = 0; j < (R + 22) / 2; j++) { const V2 v = po[j]; o[2 * j] = v.x; o[2 * j + 1] = v.y; }
@@ -290,7 +308,7 @@ __device__ __forceinline__ void fw_stage(T *smem, int c, int lane, bool emit, do
         // them one chunk later -- real outputs to the stream, the rest to the spare slot at its end: a fixed number of
         // stores per chunk, issued in front of the next prefetch
         T y[R];
-        hb45_out<T, R>(fw_arr(smem, s, plane, 1), fw_arr(smem, s, plane, 0), m0 < FW_CHUNK ? m0 : 0, y);
+        hb45_out<T, R, true>(fw_arr(smem, s, plane, 1), fw_arr(smem, s, plane, 0), m0 < FW_CHUNK ? m0 : 0, y);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const bool ok = emit && m0 + r < n_out;
