@@ -1097,10 +1097,20 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
         double g0 = s.gain, add = step_const(s), rmax = s.themax;
         int clip = s.is_clipping, ir = s.index_read, is = s.index_start;
         bool alive = true;
+#ifdef AGC_PROF
+        long long ap[4] = {0, 0, 0, 0}, ap_last = clock64(), ap_t0 = ap_last;
+        long long ac[4] = {0, 0, 0, 0};
+#define AGC_COUNT(k) ac[k]++
+#define AGC_PROBE(k) do { const long long t_ = clock64(); ap[k] += t_ - ap_last; ap_last = t_; } while (0)
+#else
+#define AGC_PROBE(k) do { } while (0)
+#define AGC_COUNT(k) do { } while (0)
+#endif
         // max of |x| over the lanes in `in`, on top of m: walk the successive record holders (usually none)
         auto walk_max = [&](double m, const double mv, const bool in) {
             unsigned long long over = __ballot(in && mv > m);
             while (over) {
+                AGC_COUNT(0);
                 m = readlane_f64(mv, (int)__ffsll((long long)over) - 1);
                 over = __ballot(in && mv > m);
             }
@@ -1119,15 +1129,6 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                 poke(&sp_rec[slot].tag, tag_of(gen, jj) | (plain ? (int)0x80000000 : 0));
             }
         };
-#ifdef AGC_PROF
-        long long ap[4] = {0, 0, 0, 0}, ap_last = clock64(), ap_t0 = ap_last;
-        long long ac[4] = {0, 0, 0, 0};
-#define AGC_COUNT(k) ac[k]++
-#define AGC_PROBE(k) do { const long long t_ = clock64(); ap[k] += t_ - ap_last; ap_last = t_; } while (0)
-#else
-#define AGC_PROBE(k) do { } while (0)
-#define AGC_COUNT(k) do { } while (0)
-#endif
         while (alive) {
             if (j < T && j / AGC_CHUNK >= f_known) f_known = uni(peek(&fetched));   // (one look per chunk, as a rule)
             bool can = j < T && j / AGC_CHUNK < f_known;
@@ -1251,7 +1252,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
             }
         }
 #ifdef AGC_PROF
-        if (lane == 0 && rx == 0) printf("agc runner: tiles %d, cycles: pre-chain %lld chain %lld post-chain %lld waiting %lld, whole wave %lld; waits: ring full %lld, chunk not fetched %lld, all made %lld\n", T, ap[0], ap[1], ap[2], ap[3], clock64() - ap_t0, ac[1], ac[2], ac[3]);
+        if (lane == 0 && rx == 0) printf("agc runner: tiles %d, cycles: pre-chain %lld chain %lld post-chain %lld waiting %lld, whole wave %lld; waits: ring full %lld, chunk not fetched %lld, all made %lld; record-walk steps %lld\n", T, ap[0], ap[1], ap[2], ap[3], clock64() - ap_t0, ac[1], ac[2], ac[3], ac[0]);
 #endif
     } else if (wave == 1) {
         // ---------------- the walker ----------------
