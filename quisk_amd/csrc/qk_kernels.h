@@ -562,7 +562,7 @@ __device__ __forceinline__ void fir_tile(const double *__restrict__ x, const T *
     for (int p = 0; p < D; p++) {
         const T *xp = lds + p * LEN + base0;
         const T *__restrict__ h = hp + p * TQP;
-#pragma unroll 1
+#pragma unroll 2
         for (int qc = 0; qc < TQP; qc += FT_QB) {
             T w[R + FT_QB - 1];
 #pragma unroll
