@@ -1289,14 +1289,21 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
                 const bool f32 = e->fp32 && st.hf;
                 FirTArgs a{in.view(), out.view(), f32 ? (const void *)st.hf : (const void *)st.h, st.TQP, first, n_out, d_list};
                 Timer tm(e, st.timer, cs);
-                const dim3 grid((n_out + FT_NTH * FT_R - 1) / (FT_NTH * FT_R), in.planes, nlist);
-                const size_t lds = (f32 ? sizeof(float) : sizeof(double)) * st.D * (FT_NTH * FT_R + st.TQP);
-#define QK_FIR(DD) case DD: if (f32) hipLaunchKernelGGL((k_fir_tiled<DD, FT_NTH, FT_R, float>), grid, dim3(FT_NTH), lds, cs, a); \
-                            else hipLaunchKernelGGL((k_fir_tiled<DD, FT_NTH, FT_R, double>), grid, dim3(FT_NTH), lds, cs, a); break
+                // outputs per lane: 5 (an LDS load feeds 3.3 FMAs) for /3 and the unit-stride filters, 3 for /2 and /5: smaller
+                // tiles, more workgroups per CU (the five-branch tile of /5 left room for five only), measured 7-10 % faster
+                // there and no different for /3 (QK_FIR_R3 = mask over D overrides, for experiments)
+                static const int r3mask = [] { const char *v = getenv("QK_FIR_R3"); return v ? atoi(v) : (1 << 2 | 1 << 5); }();    // bit D: 3 outputs per lane
+                const int rr = (r3mask >> st.D & 1) ? 3 : FT_R;
+                const dim3 grid((n_out + FT_NTH * rr - 1) / (FT_NTH * rr), in.planes, nlist);
+                const size_t lds = (f32 ? sizeof(float) : sizeof(double)) * st.D * (FT_NTH * rr + st.TQP);
+#define QK_FIRR(DD, RR) if (f32) hipLaunchKernelGGL((k_fir_tiled<DD, FT_NTH, RR, float>), grid, dim3(FT_NTH), lds, cs, a); \
+                        else hipLaunchKernelGGL((k_fir_tiled<DD, FT_NTH, RR, double>), grid, dim3(FT_NTH), lds, cs, a)
+#define QK_FIR(DD) case DD: if (rr == 3) { QK_FIRR(DD, 3); } else { QK_FIRR(DD, FT_R); } break
                 switch (st.D) {
                 QK_FIR(1); QK_FIR(2); QK_FIR(3); QK_FIR(5);
                 default: return fail(QK_EINVAL, "internal: FIR decimation factor without a kernel");
                 }
+#undef QK_FIRR
 #undef QK_FIR
             }
             break;
