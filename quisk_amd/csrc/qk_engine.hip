@@ -857,6 +857,7 @@ int drain_events(qk_engine *e)
     HIPCHECK(hipStreamSynchronize(e->fe_stream));
     HIPCHECK(hipStreamSynchronize(e->stream));
     HIPCHECK(hipStreamSynchronize(e->agc_stream));
+    if (e->apply_stream) HIPCHECK(hipStreamSynchronize(e->apply_stream));      // (a lane of class chains may carry timed kernels)
     for (auto &p : e->ev_pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, e->ev_pool[p.e0], e->ev_pool[p.e1]) != hipSuccess) continue;
