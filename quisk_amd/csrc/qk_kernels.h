@@ -198,6 +198,34 @@ __device__ __forceinline__ void hb45_out(const T *__restrict__ O, const T *__res
               "=&v"(o[19]), "=&v"(o[20]), "=&v"(o[21]), "=&v"(o[22]), "=&v"(e[0]), "=&v"(e[1])
             : "v"(ao), "v"(ae)
             : "memory");
+    } else if constexpr (sizeof(T) == 4 && (R == 6 || R == 2)) {
+        // float: the windows are read as float pairs; the compiler would pair those 8-byte reads into ds_read2_b64 (see above)
+        constexpr int NO = (R + 22) / 2, NE = R / 2;
+        unsigned long long t[NO + NE];
+        const unsigned ao = (unsigned)reinterpret_cast<size_t>(O + m0 + 2), ae = (unsigned)reinterpret_cast<size_t>(E + m0 + 12);
+        if constexpr (R == 6)
+            asm volatile(
+            "ds_read_b64 %0, %17\n\tds_read_b64 %1, %17 offset:8\n\tds_read_b64 %2, %17 offset:16\n\tds_read_b64 %3, %17 offset:24\n\t"
+            "ds_read_b64 %4, %17 offset:32\n\tds_read_b64 %5, %17 offset:40\n\tds_read_b64 %6, %17 offset:48\n\tds_read_b64 %7, %17 offset:56\n\t"
+            "ds_read_b64 %8, %17 offset:64\n\tds_read_b64 %9, %17 offset:72\n\tds_read_b64 %10, %17 offset:80\n\tds_read_b64 %11, %17 offset:88\n\t"
+            "ds_read_b64 %12, %17 offset:96\n\tds_read_b64 %13, %17 offset:104\n\tds_read_b64 %14, %18\n\tds_read_b64 %15, %18 offset:8\n\t"
+            "ds_read_b64 %16, %18 offset:16\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]), "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]), "=&v"(t[12]), "=&v"(t[13]), "=&v"(t[14]), "=&v"(t[15]), "=&v"(t[16])
+            : "v"(ao), "v"(ae) : "memory");
+        else
+            asm volatile(
+            "ds_read_b64 %0, %13\n\tds_read_b64 %1, %13 offset:8\n\tds_read_b64 %2, %13 offset:16\n\tds_read_b64 %3, %13 offset:24\n\t"
+            "ds_read_b64 %4, %13 offset:32\n\tds_read_b64 %5, %13 offset:40\n\tds_read_b64 %6, %13 offset:48\n\tds_read_b64 %7, %13 offset:56\n\t"
+            "ds_read_b64 %8, %13 offset:64\n\tds_read_b64 %9, %13 offset:72\n\tds_read_b64 %10, %13 offset:80\n\tds_read_b64 %11, %13 offset:88\n\t"
+            "ds_read_b64 %12, %14\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]), "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]), "=&v"(t[12])
+            : "v"(ao), "v"(ae) : "memory");
+#pragma unroll
+        for (int j = 0; j < NO; j++) { o[2 * j] = __uint_as_float((unsigned)t[j]); o[2 * j + 1] = __uint_as_float((unsigned)(t[j] >> 32)); }
+#pragma unroll
+        for (int j = 0; j < NE; j++) { e[2 * j] = __uint_as_float((unsigned)t[NO + j]); e[2 * j + 1] = __uint_as_float((unsigned)(t[NO + j] >> 32)); }
     } else if constexpr (R % 2 == 0) {         // m0 even: two-element vector reads (16 bytes in double, 8 in float)
         const V2 *po = reinterpret_cast<const V2 *>(__builtin_assume_aligned(O, sizeof(V2))) + (m0 / 2 + 1);
 #pragma unroll
