@@ -1290,10 +1290,11 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
                 const bool f32 = e->fp32 && st.hf;
                 FirTArgs a{in.view(), out.view(), f32 ? (const void *)st.hf : (const void *)st.h, st.TQP, first, n_out, d_list};
                 Timer tm(e, st.timer, cs);
-                // outputs per lane: 5 (an LDS load feeds 3.3 FMAs) for /3 and the unit-stride filters, 3 for /2 and /5: smaller
-                // tiles, more workgroups per CU (the five-branch tile of /5 left room for five only), measured 7-10 % faster
-                // there and no different for /3 (QK_FIR_R3 = mask over D overrides, for experiments)
-                static const int r3mask = [] { const char *v = getenv("QK_FIR_R3"); return v ? atoi(v) : (1 << 2 | 1 << 5); }();    // bit D: 3 outputs per lane
+                // outputs per lane: 5 (an LDS load feeds 3.3 FMAs), 3 for the /5 stage: its five-branch tile left room for five
+                // workgroups per CU only (10 % faster).  /2 alone gains 7 % from the smaller tile too, but its extra workgroups
+                // take that and more from the front end they run beside (headline 0.374 -> 0.389 ms), and /3 does not care
+                // (QK_FIR_R3 = mask over D overrides, for experiments)
+                static const int r3mask = [] { const char *v = getenv("QK_FIR_R3"); return v ? atoi(v) : (1 << 5); }();    // bit D: 3 outputs per lane
                 const int rr = (r3mask >> st.D & 1) ? 3 : FT_R;
                 const dim3 grid((n_out + FT_NTH * rr - 1) / (FT_NTH * rr), in.planes, nlist);
                 const size_t lds = (f32 ? sizeof(float) : sizeof(double)) * st.D * (FT_NTH * rr + st.TQP);
