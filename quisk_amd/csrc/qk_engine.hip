@@ -3,6 +3,7 @@
 // receivers, owns the streams in HBM and launches the kernels of qk_kernels.h.  Exposes the C ABI of
 // include/qk_engine.h.  No CPU fallback: every entry point that computes needs a HIP device.
 #include "../../include/qk_engine.h"
+#include <hip/hip_ext.h>
 #include "qk_kernels.h"
 #include "qk_fft.h"
 #include <algorithm>
@@ -1731,17 +1732,22 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             a.mute = e->d_sq_flag + par * e->nrx; a.kill = e->kill_audio;
             Timer tm(e, QK_KT_AGC, e->agc_stream);
             if (any_cpx) hipLaunchKernelGGL(k_agc_cabs, grid1(m_max, 1, e->nrx), dim3(256), 0, e->agc_stream, a);
-            hipLaunchKernelGGL(k_agc_gain, dim3(e->nrx), dim3(192), 0, e->agc_stream, a);
-            hipStream_t aps = e->agc_stream;
             // (short blocks are bound by the host's launches, and the second stream costs two more calls: it is used from
             // 4096 audio samples per receiver on)
             const bool own = e->apply_stream && m_max >= 4096;
+            // The gain pass sets the block period at low sample rates and runs back to back on this stream: the event the
+            // apply stream waits for rides on the kernel's own completion signal (hipExtLaunchKernelGGL) instead of a
+            // marker packet of its own behind it.
+            static const bool ext_launch = [] { const char *v = getenv("QK_AGC_EXT_LAUNCH"); return !v || atoi(v) != 0; }();
+            if (own && ext_launch) hipExtLaunchKernelGGL(k_agc_gain, dim3(e->nrx), dim3(192), 0, e->agc_stream, nullptr, e->ev_gain, 0, a);
+            else hipLaunchKernelGGL(k_agc_gain, dim3(e->nrx), dim3(192), 0, e->agc_stream, a);
+            hipStream_t aps = e->agc_stream;
             if (!own && e->last_apply_own && e->agc_pending)
                 HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_agc[par ^ 1], 0));      // the previous apply pass, on the other stream
             e->last_apply_own = own;
             agc_ev_stream = own ? e->apply_stream : e->agc_stream;
             if (own) {
-                HIPCHECK(hipEventRecord(e->ev_gain, e->agc_stream));
+                if (!ext_launch) HIPCHECK(hipEventRecord(e->ev_gain, e->agc_stream));
                 HIPCHECK(hipStreamWaitEvent(e->apply_stream, e->ev_gain, 0));
                 aps = e->apply_stream;
                 a.started = e->d_agc_started2;
