@@ -64,6 +64,13 @@ class _State:
         self.multirx_time0 = 0.0
         self.bscope_time0 = 0.0
         self.rx_mode = 3
+        self.rx_tune = self.tx_tune = 0
+        self.vfo_screen = self.vfo_audio = 0
+        self.scan = None               # change_scan's arguments while a scan is on
+        self.split_rxtx = 0
+        self.play_method = 0
+        self.play_channel = -1
+        self.f0 = None                 # filter slot 0 as last set: (fi, fq, bw, start_offset)
         self.overrange = 0
         self.read_error = 0
         self.last_counts = None
@@ -178,7 +185,11 @@ def get_audio(rx=0):
 
 def set_tune(rx_hz, tx_hz=0):
     """quisk.c:4323-4329 ("ii"): receive tuning offset from the centre of the stream; the transmit side is off the path."""
-    _st().eng.set_tune(0, int(rx_hz))
+    s = _st()
+    s.rx_tune, s.tx_tune = int(rx_hz), int(tx_hz)
+    _apply_tune_and_scan(s)
+    if s.split_rxtx:
+        _update_route(s)
 
 
 def set_rx_mode(mode):
@@ -187,6 +198,8 @@ def set_rx_mode(mode):
     s.rx_mode = int(mode)
     try:
         s.eng.set_mode(0, int(mode))
+        if s.split_rxtx:
+            _update_route(s)
     except Exception as exc:
         raise error(str(exc))
 
@@ -208,6 +221,7 @@ def set_filters(filterI, filterQ, bw, start_offset, nFilter):
     nFilter = int(nFilter)
     if nFilter == 0:
         targets = [0]
+        s.f0 = (fi, fq, int(bw), int(start_offset))
     elif nFilter == 1:
         targets = list(range(1, s.eng.n_receivers))
     else:
@@ -215,6 +229,8 @@ def set_filters(filterI, filterQ, bw, start_offset, nFilter):
     try:
         for r in targets:
             s.eng.set_filters(r, fi, fq, int(bw), int(start_offset))
+        if nFilter == 0 and s.split_rxtx:
+            _update_route(s)
     except Exception as exc:
         raise error(str(exc))
 
@@ -382,16 +398,108 @@ def set_noise_blanker(level):
     _st().eng.set_noise_blanker(int(level))
 
 
+def _update_route(s):
+    """Which receiver is heard beside receiver 0, and in which ear (quisk.c:2410-2494), as csrc/quisk_module.c does it: split
+    RX/TX demodulates the stream a second time at the transmit offset with receiver 0's mode and filter on the LAST receiver of
+    the engine; the multirx play channel is sub-receiver 1 + index."""
+    method, partner = 0, 0
+    nrx = s.eng.n_receivers
+    if 1 <= s.split_rxtx <= 4 and nrx >= 2:
+        partner = nrx - 1
+        rx_left = (s.tx_tune < s.rx_tune) if s.split_rxtx == 1 else (s.tx_tune >= s.rx_tune)       # quisk.c:2424, 2438
+        method = 0 if s.split_rxtx == 3 else 3 if s.split_rxtx == 4 else (1 if rx_left else 2)
+        s.eng.set_mode(partner, s.rx_mode)
+        s.eng.set_tune(partner, s.tx_tune)
+        if s.f0 is not None:
+            s.eng.set_filters(partner, *s.f0)
+    elif s.play_channel >= 0 and 1 + s.play_channel < nrx:
+        partner = 1 + s.play_channel
+        method = 1 if s.play_method == 1 else 2 if s.play_method == 2 else 3                        # quisk.c:2474-2493
+    s.eng.set_stereo_route(0, partner, method)
+
+
+def set_split_rxtx(split):
+    """quisk.c:4372-4379."""
+    s = _st()
+    s.split_rxtx = int(split)
+    try:
+        _update_route(s)
+    except Exception as exc:
+        raise error(str(exc))
+
+
+def set_multirx_play_method(method):
+    """quisk.c:4450-4456."""
+    s = _st()
+    s.play_method = int(method)
+    try:
+        _update_route(s)
+    except Exception as exc:
+        raise error(str(exc))
+
+
+def set_multirx_play_channel(channel):
+    """quisk.c:4458-4466: -1 = none."""
+    s = _st()
+    s.play_channel = int(channel)
+    if s.play_channel >= QUISK_MAX_RECEIVERS:
+        s.play_channel = -1
+    try:
+        _update_route(s)
+    except Exception as exc:
+        raise error(str(exc))
+
+
+def set_ssb_squelch(enabled, level):
+    """quisk.c:4356-4362."""
+    _st().eng.set_ssb_squelch(int(enabled), int(level))
+
+
+def set_auto_notch(on):
+    """quisk.c:4237-4244: the reference's notch works on bank 0."""
+    _st().eng.set_auto_notch(0, int(on))
+
+
+def set_sidetone(ctrl, volume, rit, keyup):
+    """quisk.c:4331-4346 ("idii"): of the four values the receive path uses rit_freq."""
+    if _S is not None and _S.eng is not None:
+        _S.eng.set_rit_freq(int(rit))
+
+
+def _apply_tune_and_scan(s):
+    """The mixer's offset is rx_tune_freq + vfo_screen - vfo_audio (quisk.c:2354); the scan's slots depend on the transmit
+    tune and vfo_screen (quisk.c:4661)."""
+    s.eng.set_tune(0, s.rx_tune + s.vfo_screen - s.vfo_audio)
+    if s.scan is not None and s.scan[0] > 0 and s.fft_size > 0:
+        s.eng.change_scan(*s.scan, s.tx_tune, s.vfo_screen)
+
+
+def change_rates(rate, vfo_audio, fft_rate, vfo_screen):
+    """quisk.c:3874-3886 ("iiii").  The engine's rate is fixed by record_app: another one is reported and ignored."""
+    s = _st()
+    if int(rate) != s.rate or int(fft_rate) != int(rate):
+        print("change_rates: the sample rate is fixed by record_app (%d); %d / %d ignored" % (s.rate, int(rate), int(fft_rate)))
+    s.vfo_audio, s.vfo_screen = int(vfo_audio), int(vfo_screen)
+    _apply_tune_and_scan(s)
+
+
+def change_scan(scan_blocks, scan_sample_rate, scan_valid, scan_vfo0, scan_deltaf):
+    """quisk.c:3865-3872 ("iidii")."""
+    s = _st()
+    s.scan = (int(scan_blocks), int(scan_sample_rate), float(scan_valid), int(scan_vfo0), int(scan_deltaf))
+    if s.fft_size > 0:
+        s.eng.change_scan(*s.scan, s.tx_tune, s.vfo_screen)
+
+
 def _inert(*args, **kw):
     return None
 
 
 # Entries of QuiskMethods outside the receive path: accepted and ignored.
-INERT = ("set_volume", "set_ssb_squelch", "set_auto_notch",
-         "set_split_rxtx", "set_multirx_play_method", "set_multirx_play_channel", "set_enable_bandscope",
+INERT = ("set_volume", "set_enable_bandscope",
          "add_tone", "set_spot_level", "set_imd_level", "set_key_down", "set_ctcss", "set_tx_audio", "set_record_state",
-         "set_file_name", "set_sidetone", "set_transmit_mode", "set_fdx", "set_sample_bytes",
-         "change_rate", "change_rates", "change_scan", "start_sound", "open_sound", "open_key", "close_key",
+         "set_file_name", "set_transmit_mode", "set_fdx", "set_sample_bytes",
+         "change_rate", "start_sound", "open_sound", "open_key", "close_key",
          "open_rx_udp", "close_rx_udp", "set_hermes_id", "set_hermes_filters", "set_alex_hpf", "set_alex_lpf",
          "set_hermeslite_writepointer", "clear_hermeslite_response", "set_hermeslite_writequeue", "pc_to_hermes",
          "pc_to_hermeslite_writequeue", "freedv_open", "freedv_close", "freedv_set_options", "set_freedv_mode")

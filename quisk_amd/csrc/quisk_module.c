@@ -68,6 +68,8 @@ static struct {
     int rx_mode;
     /* second-receiver routing (quisk.c:2410-2494): split_rxtx 0..4, multirx_play_method 0..2, multirx_play_channel or -1 */
     int split_rxtx, play_method, play_channel, rx_tune, tx_tune;
+    int vfo_screen, vfo_audio;                      /* change_rates, quisk.c:3874-3886 */
+    int scan_blocks, scan_rate, scan_vfo0, scan_deltaf; double scan_valid;      /* change_scan, quisk.c:3865-3872 */
     double *f0; int f0_n, f0_bw, f0_off;            /* the taps of filter slot 0, for the split partner */
 } G = { .rx_bytes = 3, .rx_endian = 1, .bs_bytes = 2, .bs_endian = 1, .use_fft = 1, .graph_refresh = 7, .rx_mode = 3, .play_channel = -1 };
 
@@ -333,13 +335,14 @@ static PyObject *get_audio(PyObject *self, PyObject *args)
     return b;
 }
 
+static int apply_tune_and_scan(void);
 static PyObject *set_tune(PyObject *self, PyObject *args)
 {   /* quisk.c:4323-4329: receive and transmit tuning offsets; the transmit side is off the path */
     int rx_hz, tx_hz;
     if (!PyArg_ParseTuple(args, "ii", &rx_hz, &tx_hz)) return NULL;
     if (!need_engine()) return NULL;
-    if (qk_set_tune(G.qk, 0, rx_hz) != QK_OK) return engine_error();
     G.rx_tune = rx_hz; G.tx_tune = tx_hz;
+    if (apply_tune_and_scan() != QK_OK) return engine_error();
     if (G.split_rxtx && update_route() != QK_OK) return engine_error();
     Py_RETURN_NONE;
 }
@@ -353,6 +356,41 @@ static PyObject *set_rx_mode(PyObject *self, PyObject *args)
     if (G.split_rxtx && update_route() != QK_OK) return engine_error();
     Py_RETURN_NONE;
 }
+/* The mixer's offset is rx_tune_freq + vfo_screen - vfo_audio (quisk.c:2354); the scan's slots depend on the transmit tune
+ * and vfo_screen (quisk.c:4661): both are applied again whenever one of their inputs changes. */
+static int apply_tune_and_scan(void)
+{
+    if (!G.qk) return QK_OK;
+    if (qk_set_tune(G.qk, 0, G.rx_tune + G.vfo_screen - G.vfo_audio) != QK_OK) return QK_EINVAL;
+    if (G.scan_blocks > 0 && G.fft_size > 0 &&
+        qk_change_scan(G.qk, G.scan_blocks, G.scan_rate, G.scan_valid, G.scan_vfo0, G.scan_deltaf, G.tx_tune, G.vfo_screen) != QK_OK)
+        return QK_EINVAL;
+    return QK_OK;
+}
+
+static PyObject *change_rates(PyObject *self, PyObject *args)
+{   /* quisk.c:3874-3886 ("iiii"): sample_rate, vfo_audio, fft_sample_rate, vfo_screen.  The engine's rate is fixed by
+     * record_app: another one is reported and ignored; the two VFOs move the mixer and the scan. */
+    int rate, vfo_audio, fft_rate, vfo_screen;
+    if (!PyArg_ParseTuple(args, "iiii", &rate, &vfo_audio, &fft_rate, &vfo_screen)) return NULL;
+    if (!need_engine()) return NULL;
+    if (rate != (int)quisk_sound_state.sample_rate || fft_rate != rate)
+        printf("change_rates: the sample rate is fixed by record_app (%d); %d / %d ignored\n", (int)quisk_sound_state.sample_rate, rate, fft_rate);
+    G.vfo_audio = vfo_audio; G.vfo_screen = vfo_screen;
+    if (apply_tune_and_scan() != QK_OK) return engine_error();
+    Py_RETURN_NONE;
+}
+
+static PyObject *change_scan(PyObject *self, PyObject *args)
+{   /* quisk.c:3865-3872 ("iidii") */
+    if (!PyArg_ParseTuple(args, "iidii", &G.scan_blocks, &G.scan_rate, &G.scan_valid, &G.scan_vfo0, &G.scan_deltaf)) return NULL;
+    if (!need_engine()) return NULL;
+    if (G.fft_size <= 0) Py_RETURN_NONE;
+    if (qk_change_scan(G.qk, G.scan_blocks, G.scan_rate, G.scan_valid, G.scan_vfo0, G.scan_deltaf, G.tx_tune, G.vfo_screen) != QK_OK)
+        return engine_error();
+    Py_RETURN_NONE;
+}
+
 static PyObject *set_split_rxtx(PyObject *self, PyObject *args)
 {   /* quisk.c:4372-4379 */
     if (!PyArg_ParseTuple(args, "i", &G.split_rxtx)) return NULL;
@@ -700,6 +738,8 @@ static PyMethodDef QuiskMethods[] = {
     { "set_split_rxtx", set_split_rxtx, METH_VARARGS, "Set split for rx/tx." },
     { "set_multirx_play_method", set_multirx_play_method, METH_VARARGS, "Select how to play audio from sub-receivers." },
     { "set_multirx_play_channel", set_multirx_play_channel, METH_VARARGS, "Select which sub-receiver to play audio." },
+    { "change_rates", change_rates, METH_VARARGS, "The VFOs of the audio and the screen (the sample rate is fixed by record_app)." },
+    { "change_scan", change_scan, METH_VARARGS, "Stitch the frames of a VFO sweep into one graph row." },
     { "key_up", key_up, METH_VARARGS, "The key went up: start the 5 ms envelope." },
     { "rx_filter_block", rx_filter_block, METH_VARARGS, "cRxFilterOut over a block of complex128 samples." },
     { "is_key_down", (PyCFunction)inert_zero, METH_VARARGS | METH_KEYWORDS, "Receive only: the key is up." },
@@ -708,7 +748,7 @@ static PyMethodDef QuiskMethods[] = {
     INERT("set_volume"), INERT("set_enable_bandscope"), INERT("add_tone"), INERT("set_spot_level"), INERT("set_imd_level"),
     INERT("set_key_down"), INERT("set_PTT"), INERT("set_ctcss"), INERT("set_tx_audio"), INERT("set_record_state"), INERT("set_file_name"),
     INERT("set_transmit_mode"), INERT("set_fdx"), INERT("set_sample_bytes"), INERT("change_rate"),
-    INERT("change_rates"), INERT("change_scan"), INERT("open_sound"), INERT("open_key"), INERT("open_rx_udp"), INERT("close_rx_udp"),
+    INERT("open_sound"), INERT("open_key"), INERT("open_rx_udp"), INERT("close_rx_udp"),
     INERT("set_hermes_id"), INERT("set_hermes_filters"), INERT("set_alex_hpf"), INERT("set_alex_lpf"), INERT("set_hermeslite_writepointer"),
     INERT("clear_hermeslite_response"), INERT("pc_to_hermes"), INERT("pc_to_hermeslite_writequeue"), INERT("freedv_open"),
     INERT("freedv_close"), INERT("freedv_set_options"), INERT("record_graph"), INERT("ImmediateChange"), INERT("set_ampl_phase"),

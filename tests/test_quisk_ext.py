@@ -213,3 +213,43 @@ def test_split_rxtx_and_multirx_play_through_the_extension():
     for o in (o_rx, o_tx, o_sub):
         o.close()
     QS.close_sound()
+
+
+@pytest.mark.gpu
+def test_change_rates_and_change_scan_through_the_extension():
+    """change_rates (quisk.c:3874-3886) moves the mixer by vfo_screen - vfo_audio (quisk.c:2354); change_scan (3865-3872) stitches
+    the frames of a sweep with the transmit tune and vfo_screen in the slot arithmetic (4661): against the oracle."""
+    fs, N, W, mode = 192000, 4096, 1024, 3
+    QS.record_app(None, _conf(), W, W, N, 64, fs, 0)
+    QS.set_params(rx_bytes=4, rx_endian=0)
+    fi, fq, bw, off = rx_filter(fs, mode)
+    QS.set_rx_mode(mode); QS.set_filters(list(fi), tuple(fq), bw, off, 0); QS.set_agc(80.0)
+    rx_tune, tx_tune, vfo_audio, vfo_screen = 21000, 7050000 - 7100000, 7098000, 7100000
+    QS.set_tune(rx_tune, tx_tune)
+    QS.change_rates(fs, vfo_audio, fs, vfo_screen)
+    orx = make_oracle_rx(fs, mode, rx_tune + vfo_screen - vfo_audio)
+    blocks = 3
+    scan = (blocks, fs, 0.84, 7000000, int(fs * 0.84))
+    QS.change_scan(*scan)
+    og = B.OracleGraph(N, W, fs)
+    og.set_passband(rx_tune + vfo_screen - vfo_audio, off, bw)
+    og.change_scan(*scan, tx_tune, vfo_screen)
+    x = make_iq(2 * blocks * N, fs, [23000, -50000, 70000], [3, 3, 4], 43)
+    worst = 0.0
+    for i in range(0, len(x), N):
+        xb = x[i:i + N]
+        QS.add_rx_samples(_raw32(xb)); assert QS.read_sound() == N
+        want = orx.process(xb)
+        got = _audio(0)
+        assert len(got) == len(want)
+        if len(want):
+            worst = max(worst, rel_err(got, want))
+    assert worst < TOL
+    og.add_frames(x)
+    time.sleep(0.01)
+    row = QS.get_graph(1, 1.0, 0.0)
+    n, want_row, _ = og.release(1.0, 0.0)
+    assert n == 2 and np.max(np.abs(np.array(row) - want_row)) < 1e-7
+    QS.change_scan(0, fs, 0.84, 0, 0)
+    orx.close(); og.close()
+    QS.close_sound()
