@@ -65,6 +65,10 @@ struct Stage {
     int hook = 0;              // audio hooks behind this stage: 1 = auto-notch and SSB squelch, 2 = auto-notch only (quisk.c:1792, 1829-1834, 1909)
     int hook_div = 1;          // the hooks' sample rate is decim_srate / hook_div (quisk_filter_srate; 48 k behind the FM chain)
     bool delayed = false;      // this stage reads its input SSQ_N samples late while the SSB squelch is on (d_delay, quisk.c:1833)
+    // Two stages on ONE state object of the reference (filtDecim5S, quisk.c:1701 and 1713): both read the same stream, the
+    // second user's samples of a block stored behind the first user's, and both move the same decimation counter
+    bool in_after = false, out_after = false;   // this stage's input / output starts behind the first user's samples of the block
+    int phase_share = -1;      // index of the stage whose `phase` is this stage's counter too
 };
 
 struct Chain {
@@ -76,6 +80,7 @@ struct Chain {
     int aud = -1;              // stream index of the 48 kHz-class mono audio
     int play = -1;             // stream index of the audio at the playback rate (AGC input)
     int n_out = 0;             // audio samples of the last block
+    int shared = -1, shared_n1 = 0;   // front chain: the stream two stages share as one ring (see Stage::in_after), the first user's count
     double *front_alt = nullptr; // front chain only: ping-pong twin of streams[0] (the front end writes block b+1 while the chain reads block b)
     int front_last_n = 0;       // samples in the twin (the last non-empty block)
     double *play_alt = nullptr; // ping-pong twin of streams[play]: the AGC of block b runs beside the chain of block b+1
@@ -409,8 +414,6 @@ static int build_front(qk_engine *e)
         for (int i = 0; i < d3; i++) r /= 3;
         for (int i = 0; i < d5; i++) r /= 5;
         resample = r >= 50000;
-        // (three /5 stages and the 24/25 resampler: the reference runs the resampler's second stage on the state object of the
-        // third /5 stage, quisk.c:1713, and the two overwrite each other; here every stage has a state of its own)
         break;
     }
     }
@@ -424,6 +427,18 @@ static int build_front(qk_engine *e)
     if (resample) {
         b.resamp(e->h_rs65, 125, 6, 5, QK_KT_DECIM);
         b.resamp(e->h_dec5, 245, 4, 5, QK_KT_DECIM);
+        if (d5 == 3) {
+            // The reference runs the resampler's second stage on filtDecim5S, the state object of the third /5 stage
+            // (quisk.c:1701, 1713): ONE ring of 245 samples and ONE decim_index serve both, so each filter sees the other's
+            // samples as its history and continues the other's counter.  Here: one stream holds, block after block, the
+            // third /5 stage's input followed by the x4/5 stage's input, both stages read it, and they share `phase`.
+            const int k3 = d3 + 2, kA = (int)c.stages.size() - 2, kB = kA + 1;      // third /5, x6/5, x4/5
+            Stream &V = c.streams[c.stages[k3].in], &X = c.streams[c.stages[kB].in];
+            V.cap += X.cap; V.hist = std::max(V.hist, X.hist);
+            c.shared = c.stages[k3].in;
+            c.stages[kA].out = c.shared; c.stages[kA].out_after = true;
+            c.stages[kB].in = c.shared; c.stages[kB].in_after = true; c.stages[kB].phase_share = k3;
+        }
     }
     c.aud = b.cur;      // "aud" of the front chain = the decimated complex stream every class reads
     c.built = true;
@@ -1281,15 +1296,19 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         const Stream &in = st.in < 0 ? input : c.streams[st.in];
         Stream &out = c.streams[st.out];
         const int n_in = in.n;
+        StreamView in_v = in.view(), out_v = out.view();
+        if (st.in_after) in_v.hist += c.shared_n1;
+        if (st.out_after) out_v.hist += c.shared_n1;
+        int &phase = st.phase_share >= 0 ? c.stages[st.phase_share].phase : st.phase;
         switch (st.kind) {
         case ST_FIR: {
-            const int n_out = (st.phase + n_in) / st.D;
-            const int first = st.D - 1 - st.phase;
-            st.phase = (st.phase + n_in) % st.D;
+            const int n_out = (phase + n_in) / st.D;
+            const int first = st.D - 1 - phase;
+            phase = (phase + n_in) % st.D;
             out.n = n_out;
             if (n_out > 0) {
                 const bool f32 = e->fp32 && st.hf;
-                FirTArgs a{in.view(), out.view(), f32 ? (const void *)st.hf : (const void *)st.h, st.TQP, first, n_out, d_list};
+                FirTArgs a{in_v, out_v, f32 ? (const void *)st.hf : (const void *)st.h, st.TQP, first, n_out, d_list};
                 Timer tm(e, st.timer, cs);
                 // outputs per lane: 5 (an LDS load feeds 3.3 FMAs), 3 for the /5 stage: its five-branch tile left room for five
                 // workgroups per CU only (10 % faster).  /2 alone gains 7 % from the smaller tile too, but its extra workgroups
@@ -1331,12 +1350,12 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         }
         case ST_RESAMP: {
             const long long span = (long long)n_in * st.L;
-            const int n_out = span > st.phase ? (int)((span - st.phase + st.D - 1) / st.D) : 0;
-            const int idx0 = st.phase;
-            st.phase = (int)(st.phase + (long long)n_out * st.D - span);
+            const int n_out = span > phase ? (int)((span - phase + st.D - 1) / st.D) : 0;
+            const int idx0 = phase;
+            phase = (int)(phase + (long long)n_out * st.D - span);
             out.n = n_out;
             if (n_out > 0) {
-                ResampArgs a{in.view(), out.view(), st.h, st.T, st.L, st.D, idx0, n_out, d_list};
+                ResampArgs a{in_v, out_v, st.h, st.T, st.L, st.D, idx0, n_out, d_list};
                 Timer tm(e, st.timer, cs);
                 hipLaunchKernelGGL(k_resample, grid1(n_out, 2, nlist), dim3(256), 0, cs, a);
             }
@@ -1412,6 +1431,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             break;
         }
         }
+        if (st.out == c.shared && !st.out_after) c.shared_n1 = out.n;     // the first user's samples of this block are in
         if (st.hook && out.n > 0) {
             const int rate = e->decim_srate / st.hook_div;
             const bool cw = &c == &e->cls_chain[CL_CW];
@@ -1426,6 +1446,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             }
         }
     }
+    if (c.shared >= 0) c.streams[c.shared].n += c.shared_n1;      // what the ring took in this block: both users' samples
     return QK_OK;
 }
 

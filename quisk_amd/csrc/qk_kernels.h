@@ -302,9 +302,14 @@ __device__ __forceinline__ void fw_carry_load(const T *smem, int s, int n_new, i
     const int l = lane < 44 ? lane : 43;
     const int sub = l / 11, i = (l % 11) * 2;               // 4 sub-arrays x 11 pairs
     const T *arr = smem + FwLayout::level_off(s) + sub * FwLayout::sub(s) + (sub & 1);
-    if constexpr (sizeof(T) == 8) {     // (two single reads, not the ds_read2_b64 the compiler would make of them: see hb45_out)
-        const unsigned ad = (unsigned)reinterpret_cast<size_t>(arr + n_new + i);
-        asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=&v"(v[0]), "=&v"(v[1]) : "v"(ad) : "memory");
+    if constexpr (sizeof(T) == 8) {
+        // Two single 8-byte reads, not the ds_read2_b64 the compiler would make of a plain pair (see hb45_out): volatile
+        // accesses in the LDS address space are not merged by the load/store optimizer, and -- unlike reads spelled out
+        // in assembly -- the compiler counts them, so it places the wait for them itself wherever v[] is first used,
+        // copied or spilled.
+        typedef volatile __attribute__((address_space(3))) const double lds_cd;
+        lds_cd *q = (lds_cd *)(arr + n_new + i);        // (generic -> LDS address space: the low 32 bits)
+        v[0] = q[0]; v[1] = q[1];
     } else {
         v[0] = arr[n_new + i]; v[1] = arr[n_new + i + 1];
     }
@@ -312,7 +317,6 @@ __device__ __forceinline__ void fw_carry_load(const T *smem, int s, int n_new, i
 template <class T>
 __device__ __forceinline__ void fw_carry_store(T *smem, int s, int lane, const T (&v)[2])
 {
-    if constexpr (sizeof(T) == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the compiler does not count the spelled-out reads)
     if (lane < 44) {
         const int sub = lane / 11, i = (lane % 11) * 2;
         T *arr = smem + FwLayout::level_off(s) + sub * FwLayout::sub(s) + (sub & 1);
