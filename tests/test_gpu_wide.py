@@ -32,10 +32,12 @@ def _wide(fs, nrx, mix, sizes, seed, carriers):
 
 
 def test_config2_width_64_usb_receivers():
-    """BASELINE configs[1] at its full width: 64 USB receivers on one 1.536 Msps stream, blocks of 2^17 and ragged ones;
-    every receiver against its own oracle (the span partition of the front end depends on the receiver count)."""
-    pr = _wide(1536000, 64, "ssb", [1 << 17, 1 << 17, 100001, 1 << 17, 7, 1 << 17], 1002, carriers=64)
-    assert pr.samples >= 64 * ((4 * (1 << 17) + 100001 + 7) // 32 - 1)      # 32 input samples per audio sample, less the stages' phases
+    """BASELINE configs[1] at its full width AND at bench.py's geometry: 64 USB receivers on one 1.536 Msps stream, blocks of
+    2^20 samples (what bench.py times; the front end's span partition depends on receiver count and block length both) and
+    ragged ones; every receiver against its own oracle."""
+    sizes = [1 << 20, 1 << 20, 100001, 7, 1 << 20]
+    pr = _wide(1536000, 64, "ssb", sizes, 1002, carriers=64)
+    assert pr.samples >= 64 * (sum(sizes) // 32 - 1)      # 32 input samples per audio sample, less the stages' phases
 
 
 def test_config4_slice_128_mixed_receivers_61440k():
