@@ -44,6 +44,12 @@ enum StageKind { ST_FIR, ST_INTERP, ST_HBINT, ST_RESAMP, ST_RXF, ST_FMDISC, ST_I
 enum ChainClass { CL_SSB = 0, CL_CW, CL_AM, CL_FM, CL_DGTW, CL_DGTIQ, CL_COUNT };    // CL_DGTW: DGT-U/L filtered at the decimated rate;
                                                                                      // CL_DGTIQ: complex (stereo) audio
 
+// The reference's filter objects that more than one mode uses (Storage[bank] of quisk_process_demodulate, quisk.c:1730-1747;
+// cRxFilterOut / dRxFilterOut rings, quisk.c:1124-1127, 1161-1165; the statics of quisk_process_samples, quisk.c:2178-2180;
+// cFracDecim's statics, quisk.c:575-576), or whose decimation counter a receiver keeps while it is in another mode.  A stage
+// that stands for one of them carries its id, so that a receiver changing chain class takes the object's contents along.
+enum ObjId { OB_NONE = -1, OB_HB5 = 0, OB_HB4, OB_D48, OB_CRX, OB_DRX, OB_HB6, OB_HB7, OB_A24P3, OB_FRAC, OB_PHB0, OB_PHB1, OB_PHB2, OB_COUNT };
+
 struct Stream {
     double *d = nullptr;
     int planes = 1, hist = 0, cap = 0, n = 0;
@@ -69,6 +75,8 @@ struct Stage {
     // second user's samples of a block stored behind the first user's, and both move the same decimation counter
     bool in_after = false, out_after = false;   // this stage's input / output starts behind the first user's samples of the block
     int phase_share = -1;      // index of the stage whose `phase` is this stage's counter too
+    long long total_in = 0;    // ST_RXF: samples this stage has taken in since the engine was made (ring positions, see RingImage)
+    int obj = OB_NONE;         // the reference's filter object this stage stands for, if a receiver can carry it between classes
 };
 
 struct Chain {
@@ -156,6 +164,16 @@ struct qk_engine {
     // per receiver
     double *d_taps = nullptr; int *d_ntaps = nullptr, *d_mode = nullptr, *d_cls = nullptr; double *d_release_gain = nullptr;
     std::vector<int> ntaps, bandwidth, start_offset;
+    // what a receiver carries between chain classes (migrate_receiver): per object the last `need` input samples of the
+    // reference's filter object, [rx][2 planes][need], and its decimation counter; cFracDecim's position
+    // The band-pass rings as the reference holds them (bufFilterI/Q and bufFilterC with their indexFilter, quisk.c:1124-1127,
+    // 1161-1165), kept on the host and brought up to date only when a receiver's filter LENGTH changes or it changes class:
+    // with a constant length the ring is a plain FIR history, which is how the kernels keep it; at a new length the ring's
+    // cells are read in another order (and cells beyond the old length come back into play), see ring_apply
+    struct RingImage { std::vector<double> cell; int idx = 0, N = 0; long long cnt = 0; bool active = false; };
+    std::vector<RingImage> rings;      // [rx][2]: cRxFilterOut's, dRxFilterOut's
+    double *d_obj[OB_COUNT] = {nullptr}; int obj_need[OB_COUNT] = {0};
+    std::vector<int> obj_phase; std::vector<double> obj_frac;
     // FM squelch and kill_audio: d_sq_state [rx][3], d_sq_flag [2][rx] (one set per block in flight towards the AGC)
     double squelch_level = -999.0; int kill_audio = 0; double *d_sq_state = nullptr, *d_sq_partial = nullptr; int *d_sq_flag = nullptr, sq_pstride = 0;
     AgcState *d_agc = nullptr; double *d_gains = nullptr, *d_agc_mag = nullptr; int gain_stride = 0;   // d_agc_mag: [rx][gain_stride] cabs of complex play streams
@@ -520,12 +538,22 @@ static int build_class(qk_engine *e, int cl)
     }
     }
     if (rc != QK_OK) return rc;
+    {   // which of the reference's objects the stages are (quisk.c:1779-1986)
+        static const int ids[CL_COUNT][8] = {
+            /* CL_SSB   */ {OB_HB5, OB_D48, OB_CRX, OB_NONE, OB_HB7, OB_NONE, OB_NONE, OB_NONE},
+            /* CL_CW    */ {OB_HB5, OB_HB4, OB_D48, OB_CRX, OB_NONE, OB_HB6, OB_HB7, OB_NONE},
+            /* CL_AM    */ {OB_D48, OB_DRX, OB_NONE, OB_NONE, OB_HB7, OB_NONE, OB_NONE, OB_NONE},
+            /* CL_FM    */ {OB_DRX, OB_NONE, OB_NONE, OB_A24P3, OB_NONE, OB_HB6, OB_NONE, OB_NONE},
+            /* CL_DGTW  */ {OB_CRX, OB_NONE, OB_NONE, OB_NONE, OB_NONE, OB_NONE, OB_NONE, OB_NONE},
+            /* CL_DGTIQ */ {OB_DRX, OB_NONE, OB_NONE, OB_NONE, OB_NONE, OB_NONE, OB_NONE, OB_NONE}};
+        for (size_t i = 0; i < c.stages.size() && i < 8; i++) c.stages[i].obj = ids[cl][i];
+    }
     c.aud = b.cur;
     // tail: fractional decimator when the decimated rate is not 48000 (quisk.c:2528-2532) ...
     if (e->decim_srate != 48000) {
         b.need_hist(b.cur, 3);
         Stage &s = b.add(ST_FRAC, cl == CL_DGTIQ ? 2 : 1, b.cur_cap + 2);
-        s.timer = T_B;
+        s.timer = T_B; s.obj = OB_FRAC;
         c.frac_cap = b.cur_cap + 8;
         HIPCHECK(hipMalloc(&c.d_frac_idx, sizeof(int) * c.frac_cap));
         HIPCHECK(hipMalloc(&c.d_frac_pos, sizeof(double) * c.frac_cap));
@@ -537,7 +565,10 @@ static int build_class(qk_engine *e, int cl)
         c.frac_dindex = 1.0;                                         // dindex = 1 (quisk.c:575)
     }
     // ... then interpolation to the play rate (quisk.c:2535-2553); mono, so one plane carries both channels
-    for (int r = e->cfg.playback_rate / 48000; r > 1; r /= 2) b.hbint(cl == CL_DGTIQ ? 2 : 1, T_B);
+    for (int r = e->cfg.playback_rate / 48000, k = 0; r > 1; r /= 2, k++) {
+        b.hbint(cl == CL_DGTIQ ? 2 : 1, T_B);
+        c.stages.back().obj = OB_PHB0 + k;          // HalfBand7..9 of quisk_process_samples (quisk.c:2178-2180)
+    }
     c.play = b.cur;
     b.need_hist(b.cur, e->cfg.playback_rate * 15 / 1000);       // AGC_DELAY, quisk.c:30, 2036
     // the class input is the front chain's output stream
@@ -583,28 +614,154 @@ static int upload_members(qk_engine *e)
 }
 
 // A receiver moves from chain class `from` to class `to` (set_rx_mode, or DGT-U/L crossing DGT_NARROW_FREQ in set_filters).
-// The reference keeps ONE AGC delay ring per bank across mode changes (Agc1, quisk.c:2181), so the 15 ms of audio in the
-// old class's play stream become the history of the new class's play stream; every other history of the receiver in the
-// new class is cleared (the reference's filter objects of the new mode hold whatever that mode last left there: stale
-// audio from before the switch, which nobody should want reproduced; DESIGN.md "Known deviations").  All streams idle.
+// The reference keeps ONE set of filter objects per bank whatever the mode (Storage[bank], quisk.c:1730-1747; the band-pass
+// rings; HalfBand7..9, Agc1 and cFracDecim's statics of quisk_process_samples): an object that the new mode uses holds what
+// the last mode that used it left there -- fresh samples if that was the old mode, stale ones from an earlier visit if not,
+// zeros if never -- and its decimation counter stands where it stopped.  Here an object's contents are the history in
+// front of its stage's input stream.  On leaving a class the receiver's objects are saved ([rx][2][need] per object); on
+// entering one they are put in front of the new class's streams.  Objects private to one class (the audio filters, the
+// one-pole states, fm_1) simply stay in that class's rows, which nothing touches while the receiver is elsewhere.
+// The counters (`phase`) belong to a class, whose receivers run in lockstep: they follow the receiver when it is the only
+// member of its new class (always so for the reference's single bank); a receiver that joins others takes their phase.
+// All streams idle.
+static double *hist_tail(qk_engine *e, Chain &c, int stream_idx, int rx, int pl, int need);
+static int ring_of_class(int cl) { return (cl == CL_SSB || cl == CL_CW || cl == CL_DGTW) ? 0 : 1; }
+static Stage *ring_stage(Chain &c) { for (auto &st : c.stages) if (st.kind == ST_RXF) return &st; return nullptr; }
+static int eff_ntaps(const qk_engine *e, int rx)
+{   // DGT-IQ is not filtered at 19 kHz and above (quisk.c:1976); N == 0 passes the samples (quisk.c:1137, 1174)
+    return (e->mode[rx] == QK_DGT_IQ && e->bandwidth[rx] >= 19000) ? 0 : e->ntaps[rx];
+}
+// Bring the host image of the ring that receiver rx's class `cl` uses up to date: the samples it has taken in since the last
+// event, written where the reference writes them (quisk.c:1139-1141, 1150).  All streams idle.
+static int ring_sync(qk_engine *e, int rx, int cl)
+{
+    Chain &c = e->cls_chain[cl];
+    Stage *st = c.built ? ring_stage(c) : nullptr;
+    if (!st || e->rings.empty()) return QK_OK;
+    qk_engine::RingImage &R = e->rings[(size_t)rx * 2 + ring_of_class(cl)];
+    const long long m = R.active ? st->total_in - R.cnt : 0;
+    R.cnt = st->total_in;
+    if (m <= 0 || R.N <= 0) return QK_OK;
+    const int N = R.N, L = (int)std::min<long long>(m, N);
+    if (R.cell.empty()) R.cell.assign((size_t)2 * e->tap_cap, 0.0);
+    std::vector<double> tail((size_t)L);
+    const int p0 = R.idx >= N ? 0 : R.idx;
+    for (int pl = 0; pl < 2; pl++) {
+        HIPCHECK(hipMemcpy(tail.data(), hist_tail(e, c, st->in, rx, pl, L), sizeof(double) * L, hipMemcpyDeviceToHost));
+        for (int j = 0; j < L; j++) {
+            const long long t = m - L + j;
+            R.cell[(size_t)pl * e->tap_cap + (size_t)((p0 + t) % N)] = tail[j];
+        }
+    }
+    R.idx = (int)((p0 + m - 1) % N) + 1;
+    return QK_OK;
+}
+// The receiver's filter length (or its class) has changed: if the ring its class uses was last run at another length, the
+// kernels' plain FIR history is replaced by the one that makes them compute what the reference computes from its ring.  The
+// reference writes the newest sample at p (p = indexFilter, or 0 when that is beyond the new length, quisk.c:1139-1140) and
+// sums f[k] ring[(p + k) mod N] (quisk.c:1144-1149): in the kernels' order (h[0] = f[0], h[m] = f[N - m]) tap m meets cell
+// (p - m) mod N, which holds x[n - m] once the ring has gone round at this length and whatever the old length left there
+// until then.  So the history handed to the kernels is x'[-m] = cell[(p - m) mod N], m = 1 .. N-1.
+static int ring_apply(qk_engine *e, int rx)
+{
+    const int cl = e->cls[rx];
+    Chain &c = e->cls_chain[cl];
+    Stage *st = c.built ? ring_stage(c) : nullptr;
+    if (!st) return QK_OK;
+    if (e->rings.empty()) e->rings.resize((size_t)e->nrx * 2);
+    qk_engine::RingImage &R = e->rings[(size_t)rx * 2 + ring_of_class(cl)];
+    const int N = eff_ntaps(e, rx);
+    R.cnt = st->total_in;
+    R.active = N > 0;
+    if (N <= 0 || N == R.N) return QK_OK;
+    const int p = R.idx >= N ? 0 : R.idx, H = e->tap_cap;
+    std::vector<double> hist((size_t)H, 0.0);
+    for (int pl = 0; pl < 2; pl++) {
+        std::fill(hist.begin(), hist.end(), 0.0);
+        if (!R.cell.empty())
+            for (int m = 1; m < N; m++) hist[(size_t)H - m] = R.cell[(size_t)pl * H + (size_t)(((p - m) % N + N) % N)];
+        HIPCHECK(hipMemcpy(hist_tail(e, c, st->in, rx, pl, H), hist.data(), sizeof(double) * H, hipMemcpyHostToDevice));
+    }
+    R.N = N;
+    return QK_OK;
+}
+
+static int obj_need_of(const qk_engine *e, int ob)
+{
+    switch (ob) {
+    case OB_HB5: case OB_HB4: return 44;
+    case OB_D48: return 98;
+    case OB_CRX: case OB_DRX: return e->tap_cap;
+    case OB_HB6: case OB_HB7: case OB_PHB0: case OB_PHB1: case OB_PHB2: return 22;
+    case OB_FRAC: return 4;
+    default: return 0;
+    }
+}
+// where the last `need` samples in front of the next block of stream `s` (row rx, plane pl) lie
+static double *hist_tail(qk_engine *e, Chain &c, int stream_idx, int rx, int pl, int need)
+{
+    const bool chain_in = stream_idx < 0;
+    Chain &owner = chain_in ? e->front : c;
+    const int si = chain_in ? e->front.aud : stream_idx;
+    Stream &s = owner.streams[si];
+    double *row = s.d + (long long)rx * s.rx_stride() + (long long)pl * (s.hist + s.cap);
+    // the front end's own output stream is double-buffered: the next block's head copy takes the history from behind the last
+    // block in the current buffer; every other stream has had its tail moved to the front already
+    if (&owner == &e->front && si == 0 && owner.front_last_n > 0) return row + s.hist + owner.front_last_n - need;
+    return row + s.hist - need;
+}
+static int migrate_objects(qk_engine *e, int rx, Chain &c, bool save, bool adopt_phase)
+{
+    for (auto &st : c.stages) {
+        if (st.obj < 0) continue;
+        const int ob = st.obj, need = e->obj_need[ob];
+        if (st.kind == ST_FIR && st.D > 1) {
+            if (save) e->obj_phase[(size_t)rx * OB_COUNT + ob] = st.phase;
+            else if (adopt_phase) st.phase = e->obj_phase[(size_t)rx * OB_COUNT + ob];
+        }
+        if (st.kind == ST_FRAC) {
+            if (save) e->obj_frac[rx] = c.frac_dindex;
+            else if (adopt_phase) c.frac_dindex = e->obj_frac[rx];
+        }
+        if (need <= 0) continue;
+        const Stream &in = st.in < 0 ? e->front.streams[e->front.aud] : c.streams[st.in];
+        if (in.hist < need) return fail(QK_EINVAL, "internal: stream history shorter than the object it stands for");
+        for (int pl = 0; pl < 2; pl++) {
+            double *obj = e->d_obj[ob] + ((size_t)rx * 2 + pl) * need;
+            double *str = hist_tail(e, c, st.in, rx, pl < in.planes ? pl : 0, need);      // mono audio is both channels
+            if (save) HIPCHECK(hipMemcpyAsync(obj, str, sizeof(double) * need, hipMemcpyDeviceToDevice, e->stream));
+            else if (pl < in.planes) HIPCHECK(hipMemcpyAsync(str, obj, sizeof(double) * need, hipMemcpyDeviceToDevice, e->stream));
+        }
+    }
+    return QK_OK;
+}
 static int migrate_receiver(qk_engine *e, int rx, int from, int to)
 {
     Chain &n = e->cls_chain[to];
     if (!n.built) return QK_OK;
-    for (auto &s : n.streams)
-        HIPCHECK(hipMemsetAsync(s.d + (long long)rx * s.rx_stride(), 0, sizeof(double) * s.rx_stride(), e->stream));
-    Stream &np = n.streams[n.play];
-    HIPCHECK(hipMemsetAsync(n.play_alt + (long long)rx * np.rx_stride(), 0, sizeof(double) * np.rx_stride(), e->stream));
-    for (auto &st : n.stages)
-        if (st.iir_state) HIPCHECK(hipMemsetAsync(st.iir_state + 2 * rx, 0, 2 * sizeof(double), e->stream));
-    if (to == CL_FM) {      // fm_1 = 10 (quisk.c:1763), as at creation
-        Stream &f = n.streams[n.stages[0].out];
-        const double ten = 10.0;
-        HIPCHECK(hipMemcpyAsync(f.d + (long long)rx * f.rx_stride() + f.hist - 1, &ten, sizeof(double), hipMemcpyHostToDevice, e->stream));
-        HIPCHECK(hipStreamSynchronize(e->stream));
+    if (e->obj_phase.empty()) {
+        e->obj_phase.assign((size_t)e->nrx * OB_COUNT, 0);
+        e->obj_frac.assign((size_t)e->nrx, 1.0);                                   // dindex = 1 (quisk.c:575)
+        for (int ob = 0; ob < OB_COUNT; ob++) {
+            e->obj_need[ob] = obj_need_of(e, ob);
+            if (e->obj_need[ob] <= 0) continue;
+            const size_t bytes = sizeof(double) * (size_t)e->nrx * 2 * e->obj_need[ob];
+            HIPCHECK(hipMalloc(&e->d_obj[ob], bytes));
+            HIPCHECK(hipMemsetAsync(e->d_obj[ob], 0, bytes, e->stream));           // never used: zeros (quisk.c:1751-1762)
+        }
     }
     Chain &o = e->cls_chain[from];
+    if (from != to && o.built) {
+        int rc = ring_sync(e, rx, from);
+        if (rc == QK_OK) rc = migrate_objects(e, rx, o, true, false);
+        if (rc != QK_OK) return rc;
+    }
+    { int rc = migrate_objects(e, rx, n, false, n.members.size() == 1); if (rc != QK_OK) return rc; }
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    { int rc = ring_apply(e, rx); if (rc != QK_OK) return rc; }
+    Stream &np = n.streams[n.play];
     if (from != to && o.built && e->agc_started[rx]) {
+        // Agc1's delay ring (quisk.c:2181): the 15 ms of audio in the old class's play stream
         Stream &op = o.streams[o.play];
         const int h = std::min(op.hist, np.hist);
         for (int pl = 0; pl < np.planes; pl++) {
@@ -1363,6 +1520,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         }
         case ST_RXF: {
             out.n = n_in;
+            st.total_in += n_in;
             if (n_in > 0) {
                 RxfArgs a{in.view(), out.view(), e->fp32 ? (const void *)e->d_taps_f : (const void *)e->d_taps, e->d_ntaps, e->d_mode, e->tap_cap, n_in,
                           st.rxf_kind, d_list};
@@ -1889,6 +2047,7 @@ void qk_destroy(qk_engine *e)
     if (e->d_route_tmp) hipFree(e->d_route_tmp);
     for (void *p : {(void *)e->d_ssb_carry, (void *)e->d_ssb_state, (void *)e->d_bw, (void *)e->d_notch_on, (void *)e->d_notch}) if (p) hipFree(p);
     for (auto &r : e->routes) for (auto &q : r.fifo) for (double *p : q) if (p) hipFree(p);
+    for (double *p : e->d_obj) if (p) hipFree(p);
     for (void *p : {(void *)e->d_scan_avg, (void *)e->d_raw_rows, (void *)e->d_rfb_x[0], (void *)e->d_rfb_x[1], (void *)e->d_rfb_x[2], (void *)e->d_rfb_y, (void *)e->d_rfb_t}) if (p) hipFree(p);
     for (auto &ev : e->ev_pool) if (ev) hipEventDestroy(ev);
     if (e->agc_stream) { hipStreamSynchronize(e->agc_stream); hipStreamDestroy(e->agc_stream); }
@@ -1966,6 +2125,7 @@ int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int
     if (n > e->tap_cap)
         return fail(QK_ERANGE, "filter longer than the engine's tap capacity (qk_config.reserved[0])");
     SYNC_ALL(e);
+    { int rcr = ring_sync(e, rx, e->cls[rx]); if (rcr != QK_OK) return rcr; }
     {   // the tap order of cRxFilterOut (quisk.c:1176-1186) as a plain FIR: h[0] = f[0], h[m] = f[n - m]; zero-padded
         std::vector<double> hp((size_t)2 * e->tap_cap, 0.0);
         for (int m = 0; m < n; m++) {
@@ -1988,7 +2148,7 @@ int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int
         int rcm = upload_members(e);
         return rcm != QK_OK ? rcm : migrate_receiver(e, rx, from, cl);
     }
-    return QK_OK;
+    return ring_apply(e, rx);
 }
 
 int qk_set_dc_remove(qk_engine *e, int bandwidth)
