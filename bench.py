@@ -11,6 +11,8 @@ Further legs in the same JSON line (each with its own roofline object):
                  N > 1 ranks the audio of all receivers is gathered to rank 0 over RCCL and that gather is timed
   config5_slice  the per-GPU share of configs[4]: the same slice in fp32 mode with a 2^20-point FFT of every block beside it
   spectrum       configs[2]: 2^20-point windowed, averaged display FFT at 61.44 Msps (rank 0), CPU FFT timed beside it
+  config4_one_gpu  the WHOLE of configs[3] on one GPU: 1024 mixed receivers at 61.44 Msps with the fp64 2^20-point FFT of every
+                 block beside them -- does the north-star target fit one MI355X in real time? (N = 1 only)
   config1        configs[0]: 1 USB receiver at 192 ksps in 960-sample blocks, engine beside the single-threaded CPU port
   cpu_baseline   the CPU port (oracle) of the headline workload on the host cores (rank 0, N = 1 only)
 
@@ -55,6 +57,7 @@ def parse():
     ap.add_argument("--no-config4", action="store_true", help="skip the configs[3] per-GPU slice leg")
     ap.add_argument("--no-config1", action="store_true", help="skip the configs[0] leg")
     ap.add_argument("--no-config5", action="store_true", help="skip the configs[4] fp32 slice leg")
+    ap.add_argument("--no-one-gpu", action="store_true", help="skip the 1024-receivers-on-one-GPU leg")
     ap.add_argument("--cpu-samples", type=int, default=1 << 21)
     return ap.parse_args()
 
@@ -70,7 +73,7 @@ def launch_ranks(a):
 
 
 # ------------------------------------------------------------------------------------------------ CPU legs
-def cpu_baseline(fs, modes, tunes, n_samples, seed):
+def cpu_baseline(fs, modes, tunes, n_samples, seed, note=""):
     """The oracle (CPU restatement of the reference's per-sample loops, kind "port") on the host cores:
     one receiver per thread, blocks of 65536 like config 2.  Test infrastructure used as the checker's clock only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -92,9 +95,67 @@ def cpu_baseline(fs, modes, tunes, n_samples, seed):
     for o in rxs:
         o.close()
     return {"value": n_samples / dt / 1e6, "unit": "input Msamples/s at %d receivers" % len(modes), "cores": cores,
-            "kind": "port",
-            "sample": "%d receivers x %d I/Q samples (%.2f s of signal) in 65536-sample blocks, one receiver per thread"
-                      % (len(modes), n_samples, n_samples / fs)}
+            "kind": "port", "realtime_factor": n_samples / dt / fs,
+            "sample": "%d receivers x %d I/Q samples (%.4f s of signal) in 65536-sample blocks, one receiver per thread%s"
+                      % (len(modes), n_samples, n_samples / fs, note)}
+
+
+def reference_calibration(n=1 << 21):
+    """What "kind: port" is worth against the reference's own code: the decimation chain of config 2 -- quisk_cDecim2HB45 x 4
+    then quisk_cDecimate with the 98-tap filter, / 2 (filter.c:354-394, 180-206; quisk.c:1649-1668, 1706) -- over the same
+    samples on one thread, once through oracle/_ref (the reference's filter.c compiled unmodified; it travels with the tree as
+    a built library) and once through the port.  None where oracle/_ref is absent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import _bind as B
+    if not B.have_ref():
+        return None
+    rng = np.random.default_rng(7)
+    x = np.round((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 2.0 ** 20)
+    h = B.oracle_table("qk_h_dec2_98")
+    R, O = B.ref(), B.oracle()
+
+    def run_ref():
+        w = x.copy(); m = n
+        hbs = [B.RCHB() for _ in range(4)]
+        f = B.RCFilter()
+        R.quisk_filt_cInit(C.byref(f), h.ctypes.data_as(B.c_dp), len(h))
+        t0 = time.perf_counter()
+        for hb in hbs:
+            m = R.quisk_cDecim2HB45(w, m, C.byref(hb))
+        m = R.quisk_cDecimate(w, m, C.byref(f), 2)
+        return time.perf_counter() - t0, w[:m].copy()
+
+    def run_port():
+        w = x.copy(); m = n
+        hbs = [B.OCHB() for _ in range(4)]
+        f = B.OCFir()
+        O.qko_cfir_init(C.byref(f), h.ctypes.data_as(B.c_dp), len(h))
+        t0 = time.perf_counter()
+        for hb in hbs:
+            m = O.qko_cdecim2hb45(w, m, C.byref(hb))
+        m = O.qko_cdecimate(w, m, C.byref(f), 2)
+        return time.perf_counter() - t0, w[:m].copy()
+
+    run_ref(); run_port()
+    tr, yr = min((run_ref() for _ in range(3)), key=lambda p: p[0])
+    tp, yp = min((run_port() for _ in range(3)), key=lambda p: p[0])
+    return {"chain": "quisk_cDecim2HB45 x 4 -> quisk_cDecimate(98 taps, / 2), %d complex samples, one thread, best of 3" % n,
+            "reference_msamples_per_s": n / tr / 1e6, "port_msamples_per_s": n / tp / 1e6, "port_over_reference": tr / tp,
+            "kind": "reference", "bit_identical": bool(np.array_equal(yr.view(np.float64), yp.view(np.float64)))}
+
+
+def rocprof_kernel_ms(summary_csv, needle):
+    """Average duration (ms) of the kernel whose name contains `needle` in a committed rocprofv3 --kernel-trace --stats summary
+    (profiles/*.csv), or None."""
+    import csv
+    path = os.path.join(ROOT, "profiles", summary_csv)
+    if not os.path.exists(path):
+        return None
+    for r in csv.DictReader(open(path)):
+        if needle in r.get("Name", ""):
+            return float(r["AverageNs"]) / 1e6
+    return None
 
 
 def cpu_fft_baseline(N, frames_single=3, frames_multi=16):
@@ -158,7 +219,7 @@ def timed_leg(eng, ptrs, block, steps, warmup, barrier, timing_groups):
     return dt, st
 
 
-def frontend_roofline(st, fs, block, nrx, dt_step_ms, fp32, pmc_name):
+def frontend_roofline(st, fs, block, nrx, dt_step_ms, fp32, pmc_name, rocprof_csv=None):
     from quisk_amd import plan_decimation
     from quisk_amd.engine import KT_FRONTEND
     _, d2, _, _ = plan_decimation(fs)
@@ -176,7 +237,14 @@ def frontend_roofline(st, fs, block, nrx, dt_step_ms, fp32, pmc_name):
         except Exception:
             traffic = None
     esz = 8 if fp32 else 16
-    return {"kernel": "k_frontend_wave<S=%d> (mixer + %d fused half-band decimators)" % (S, S),
+    # the same kernel's average duration in the committed rocprofv3 summary of this command: the HIP-event figure includes the
+    # wait of the second event behind other queues' packets, the profiler's is the kernel's own begin-to-end time
+    rp_ms = rocprof_kernel_ms(rocprof_csv, "k_frontend_wave<%d, %s>" % (S, "float" if fp32 else "double")) if rocprof_csv else None
+    rp = None
+    if rp_ms:
+        rp = {"avg_launch_ms": rp_ms, "achieved": fe_flops / (rp_ms * 1e-3) / 1e12, "frac": fe_flops / (rp_ms * 1e-3) / 1e12 / peak,
+              "source": "profiles/%s (rocprofv3 --kernel-trace --stats of an earlier run of this command)" % rocprof_csv}
+    return {"kernel": "k_frontend_wave<S=%d> (mixer + %d fused half-band decimators)" % (S, S), "rocprof": rp,
             "bound": "valu", "pipe": "fp32 vector FMA" if fp32 else "fp64 vector FMA", "achieved": achieved_tf, "peak": peak,
             "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic, "traffic_source": source,
             "avg_launch_ms": fe_ms, "launches": int(st.kernel_launches[KT_FRONTEND]),
@@ -243,11 +311,11 @@ def spectrum_leg(local, dev_block_ptrs, block, with_cpu):
     gbs = fps * N * 16.0 / 1e9
     k_gbs = N * 16.0 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     traffic, source = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_fft.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_fft.json")
     if os.path.exists(pmc):
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_frame")
-            source = "profiles/r02_pmc_fft.json (rocprofv3 --pmc passes of an earlier run, not this run)"
+            source = "profiles/r03_pmc_fft.json (rocprofv3 --pmc passes of an earlier run, not this run)"
         except Exception:
             traffic = None
     res = {"workload": "BASELINE configs[2]: 2^20-point windowed FFT at 61.44 Msps, 8-frame magnitude average, 4096-point dB row",
@@ -398,7 +466,7 @@ def main():
                            "2^20-sample blocks, AGC" % nrx4,
                "value": v4, "unit": "Msamples/s", "steps": k4, "ms_per_step": dt4 / k4 * 1e3, "n_gpus": world,
                "receivers_total": nrx4 * world, "realtime_factor": v4 * 1e6 / world / fs4,
-               "roofline": frontend_roofline(st4, fs4, block, nrx4, dt4 / k4 * 1e3, a.fp32, "r02_pmc_frontend_c4.json")}
+               "roofline": frontend_roofline(st4, fs4, block, nrx4, dt4 / k4 * 1e3, a.fp32, "r03_pmc_frontend_c4.json", "r03_kernel_stats_default_bench.csv")}
         if world > 1:
             leg["gather"] = gather_outputs(eng4, nrx4)
         later.append(eng4)       # (closed behind the headline leg: freeing its buffers would idle the GPU in front of it)
@@ -425,8 +493,26 @@ def main():
             "row_finite": bool(row5 is not None and np.isfinite(row5).all()),
             "tolerance": "tests/test_gpu_fp32.py: audio in front of the AGC <= 1e-5 relative RMS (floor 1e-8 of the stream's peak), "
                          "spectrum <= 0.01 dB, against the fp64 oracle",
-            "roofline": frontend_roofline(st5, fs5, block, nrx5, dt5 / k5 * 1e3, True, "r02_pmc_frontend_c5.json")}
+            "roofline": frontend_roofline(st5, fs5, block, nrx5, dt5 / k5 * 1e3, True, "r03_pmc_frontend_c5.json", "r03_kernel_stats_default_bench.csv")}
         later.append(eng5)
+
+    # ---- the whole of configs[3] on ONE GPU: 1024 mixed receivers at 61.44 Msps + the fp64 2^20-point FFT of every block ----
+    if not a.no_one_gpu and not a.no_config4 and world == 1 and block >= (1 << 20):
+        fs6, nrx6, N6 = 61440000, 1024, 1 << 20
+        eng6 = make_engine(fs6, nrx6, block, local, tune_offsets(nrx6, fs6), mode_mix(nrx6, "mixed"), fp32=a.fp32, fft_size=N6, data_width=4096)
+        k6 = min(a.steps, 20)
+        dt6, st6 = timed_leg(eng6, ptrs, block, k6, 2, barrier, (KT_FRONTEND,))
+        frames6, row6, _ = eng6.get_graph(1.0, 0.0)
+        v6 = k6 * block / dt6 / 1e6
+        res["config4_one_gpu"] = {
+            "workload": "BASELINE configs[3] whole on ONE GPU: %d mixed SSB/AM/FM receivers at 61.44 Msps, 2^20-sample blocks, AGC, "
+                        "with a 2^20-point fp64 windowed FFT of every block beside them" % nrx6,
+            "value": v6, "unit": "Msamples/s", "steps": k6, "ms_per_step": dt6 / k6 * 1e3, "n_gpus": 1, "receivers_total": nrx6,
+            "realtime_factor": v6 * 1e6 / fs6, "fits_one_gpu_in_real_time": bool(v6 * 1e6 / fs6 >= 1.0),
+            "fft_frames_per_s": float(st6.fft_frames) / dt6 if dt6 > 0 else 0.0,
+            "row_finite": bool(row6 is not None and np.isfinite(row6).all()),
+            "roofline": frontend_roofline(st6, fs6, block, nrx6, dt6 / k6 * 1e3, a.fp32, "r03_pmc_frontend_c4.json")}
+        eng6.close()
 
     dt, st = timed_leg(eng, ptrs, block, a.steps, a.warmup, barrier, (KT_FRONTEND,))
     dt = max_over_ranks(dt, torch.device("cuda", local))
@@ -445,7 +531,7 @@ def main():
                    "block_samples": block, "receivers_total": total_rx, "sample_rate": fs, "sharding": "receivers"},
         "realtime_factor": value * 1e6 / world / fs,
         "receiver_msamples_per_s": value * nrx,
-        "roofline": frontend_roofline(st, fs, block, nrx, step_ms, a.fp32, "r02_pmc_frontend_c2.json"),
+        "roofline": frontend_roofline(st, fs, block, nrx, step_ms, a.fp32, "r03_pmc_frontend_c2.json", "r03_kernel_stats_default_bench.csv"),
     }
     res["after_idle"] = {"ms_per_step": dt_idle / a.steps * 1e3, "value": a.steps * block * world / dt_idle / 1e6,
                          "note": "the same leg run first, straight after set-up: the GPU's clocks are still coming up from idle"}
@@ -465,6 +551,28 @@ def main():
         res["config1"] = config1_leg(local, with_cpu)
     if with_cpu:
         res["cpu_baseline"] = cpu_baseline(fs, modes, tunes, a.cpu_samples, 1002)
+        res["cpu_baseline"]["reference_calibration"] = reference_calibration()
+        if "config4_slice" in res:
+            fs4, nrx4 = 61440000, 128
+            c4 = cpu_baseline(fs4, mode_mix(nrx4, "mixed"), tune_offsets(nrx4, fs4), 1 << 18, 1004)
+            res["config4_slice"]["cpu_baseline"] = c4
+            if "config5_slice" in res:
+                fft = res.get("spectrum", {}).get("cpu_baseline")
+                c5 = dict(c4)
+                c5["sample"] += "; the port computes in fp64 (the reference has no fp32 mode)"
+                if fft:     # one 2^20-point frame per 2^20-sample block, after the receivers, on the same cores
+                    t_blk = (1 << 20) / (c4["value"] * 1e6) + 1.0 / fft["value"]
+                    c5["value"] = (1 << 20) / t_blk / 1e6
+                    c5["realtime_factor"] = c5["value"] * 1e6 / fs4
+                    c5["sample"] += " + the oracle's 2^20-point FFT of every block (%.1f frames/s on %d cores)" % (fft["value"], fft["cores"])
+                res["config5_slice"]["cpu_baseline"] = c5
+            if "config4_one_gpu" in res:
+                c6 = dict(c4)
+                c6["value"] = c4["value"] * nrx4 / 1024.0
+                c6["realtime_factor"] = c6["value"] * 1e6 / fs4
+                c6["unit"] = "input Msamples/s at 1024 receivers"
+                c6["sample"] = "scaled from the 128-receiver run above (receivers are independent: 1024 take 8 times as long); FFT not included"
+                res["config4_one_gpu"]["cpu_baseline"] = c6
     if world > 1:
         dist.barrier()
     if rank == 0:

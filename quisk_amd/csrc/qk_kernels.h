@@ -1886,37 +1886,46 @@ __global__ __launch_bounds__(256) void k_copy_c(const double2 *src, double2 *dst
 // ------------------------------------------------------------------------------------------------
 // Second-receiver routing (quisk.c:2410-2494): the audio of receiver `rx` becomes stereo, one channel its own audio and
 // the other the audio of a partner receiver (split RX/TX: the same stream tuned to the transmit frequency; or the
-// sub-receiver chosen by set_multirx_play_channel), count-equalised by the two FIFOs of Buffer2Chan (quisk.c:1452-1487).
-// Both inputs are the receivers' mono output rows behind their AGCs (the reference runs Agc1 / Agc2 on the two channels
-// separately, quisk.c:2563-2572: each channel's gain follows its own audio, as here).
-// method 1: left = rx, right = partner; 2: left = partner, right = rx; 3: both channels = partner.
+// sub-receiver chosen by set_multirx_play_channel).  In the reference's order: the two DETECTED streams (at the decimated
+// rate, in front of cFracDecim and the play-rate interpolators) are count-equalised by the two FIFOs of Buffer2Chan
+// (quisk.c:1452-1487) and become the real and imaginary part of one stereo stream (k_route_pair: rows 0 = left, 1 = right of
+// the route's own tail chain), which then goes through cFracDecim, the interpolators and -- each channel by itself --
+// Agc1 (left) and Agc2 (right) (quisk.c:2528-2572); k_route_combine puts the two channels into the receiver's output row
+// with the per-channel squelch of quisk.c:2590-2601.
+// method 1: left = rx, right = partner; 2: left = partner, right = rx; 3: both channels = partner; 4: both = rx.
 // ------------------------------------------------------------------------------------------------
 struct RouteArgs {
-    double2 *out; long long out_stride;
+    StreamView in_a, in_b;              // the detected audio of receiver rx and of the partner (plane 0), rows rx / partner
     int rx, partner, method;
     const double *fifo_a, *fifo_b;      // samples waiting from earlier blocks (a: receiver rx, b: the partner)
     double *next_a, *next_b;            // what stays behind after this block
     int nbuf_a, nbuf_b, ca, cb, nout;
-    double2 *tmp;
+    StreamView out;                     // the pair: row 0 = left, row 1 = right
 };
-__global__ __launch_bounds__(256) void k_route_mix(RouteArgs r)
+__global__ __launch_bounds__(256) void k_route_pair(RouteArgs r)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int ta = r.nbuf_a + r.ca, tb = r.nbuf_b + r.cb;
     double a = 0.0, b = 0.0;
-    if (i < ta) a = i < r.nbuf_a ? r.fifo_a[i] : r.out[(long long)r.rx * r.out_stride + (i - r.nbuf_a)].x;
-    if (i < tb) b = i < r.nbuf_b ? r.fifo_b[i] : r.out[(long long)r.partner * r.out_stride + (i - r.nbuf_b)].x;
+    if (i < ta) a = i < r.nbuf_a ? r.fifo_a[i] : sv_ptr(r.in_a, r.rx, 0)[i - r.nbuf_a];
+    if (i < tb) b = i < r.nbuf_b ? r.fifo_b[i] : sv_ptr(r.in_b, r.partner, 0)[i - r.nbuf_b];
     if (i < r.nout) {
-        r.tmp[i] = r.method == 1 ? make_double2(a, b) : r.method == 2 ? make_double2(b, a) : make_double2(b, b);
+        sv_ptr(r.out, 0, 0)[i] = (r.method == 1 || r.method == 4) ? a : b;
+        sv_ptr(r.out, 1, 0)[i] = (r.method == 2 || r.method == 4) ? a : b;
     } else {
         if (i < ta) r.next_a[i - r.nout] = a;
         if (i < tb) r.next_b[i - r.nout] = b;
     }
 }
-__global__ __launch_bounds__(256) void k_route_store(RouteArgs r)
+// left / right: the two channels' rows behind their AGCs (mono pairs: .x is the sample); mute_l / mute_r: the squelch flags of
+// the receivers the channels came from (quisk.c:2421-2493)
+__global__ __launch_bounds__(256) void k_route_combine(const double2 *left, const double2 *right, double2 *out, int n,
+                                                       const int *mute_l, const int *mute_r, int kill)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < r.nout) r.out[(long long)r.rx * r.out_stride + i] = r.tmp[i];
+    if (i >= n) return;
+    const bool ml = kill || (mute_l && *mute_l), mr = kill || (mute_r && *mute_r);
+    out[i] = make_double2(ml ? 0.0 : left[i].x, mr ? 0.0 : right[i].x);
 }
 // Key-up envelope (quisk.c:2602-2612): the first samples behind a key-up are scaled by a ramp that the host has made with
 // the reference's own additions (env += 1 / (rate * 5 ms), stopping at 1); every receiver's output row gets it.
