@@ -96,16 +96,20 @@ int qk_set_ssb_squelch(qk_engine *e, int enabled, int level);
 int qk_set_auto_notch(qk_engine *e, int rx, int on);
 int qk_set_rit_freq(qk_engine *e, int hz);
 int qk_is_squelch(qk_engine *e, int freq);
-/* Second-receiver routing (quisk.c:2410-2494): the output of receiver rx becomes stereo, made of its own audio and the
- * audio of partner_rx, both behind their own AGCs (the reference's Agc1 / Agc2, quisk.c:2563-2572), with the counts of the two
- * equalised by Buffer2Chan's FIFOs (quisk.c:1452-1487; BUF2CHAN_SIZE scaled to the play rate).
+/* Second-receiver routing (quisk.c:2410-2494): the output of receiver rx becomes stereo, made of its own detected audio and that
+ * of partner_rx, in the reference's order: the two streams' counts are equalised by Buffer2Chan's FIFOs at the decimated rate
+ * (quisk.c:1452-1487, 2419, 2473), the pair goes through cFracDecim and the play-rate interpolators (quisk.c:2528-2553), then
+ * Agc1 -- the receiver's own AGC, which carries on from mono -- runs on the left channel and Agc2 on the right
+ * (quisk.c:2563-2572).
  *   method 1  left = rx, right = partner   (split_rxtx 1 / 2 with the receive side left; multirx_play_method 1)
  *   method 2  left = partner, right = rx   (split_rxtx 1 / 2 with the receive side right; multirx_play_method 2)
  *   method 3  both channels = partner      (split_rxtx 4; multirx_play_method 0)
- *   method 0  off: mono on both channels   (also split_rxtx 3)
- * Split RX/TX: the partner is a receiver on the same stream tuned to the transmit offset with receiver rx's mode and filter
- * (quisk.c:2410-2418); multirx play: the sub-receiver of set_multirx_play_channel.  A squelched or killed source is silent
- * in its own channel only (quisk.c:2585-2601).  The partner keeps its own output row. */
+ *   method 4  both channels = rx, through the stereo path and its two AGCs (split_rxtx 3)
+ *   method 0  off: mono on both channels
+ * Split RX/TX: the partner is a receiver on the same stream tuned to the transmit offset + RIT with receiver rx's mode and
+ * filter (quisk.c:2410-2418); multirx play: the sub-receiver of set_multirx_play_channel.  A squelched or killed source is
+ * silent in its own channel only (quisk.c:2585-2601).  The partner keeps its own (mono) output row.  While rx is in DGT-IQ,
+ * which is stereo by itself, the route rests (quisk.c:2407-2409).  At most 4 routes per engine. */
 int qk_set_stereo_route(qk_engine *e, int rx, int partner_rx, int method);
 /* The key went up (quisk.c:2240-2241): the next 5 ms of every receiver's output are raised along the reference's ramp
  * (keyupEnvelope, quisk.c:2602-2612). */
@@ -223,7 +227,7 @@ int qk_reset_stats(qk_engine *e);
 
 /* Stage taps for parity tests (debug): copy the planar output of an internal stream to the host.
  * which: QK_TAP_*; out: [planes][count] doubles; returns count per plane. */
-enum { QK_TAP_FRONTEND = 0, QK_TAP_DECIM = 1, QK_TAP_DEMOD = 2, QK_TAP_AUDIO48 = 3, QK_TAP_PLAY = 4 };
+enum { QK_TAP_FRONTEND = 0, QK_TAP_DECIM = 1, QK_TAP_DEMOD = 2, QK_TAP_AUDIO48 = 3, QK_TAP_PLAY = 4, QK_TAP_ROUTE = 5 };
 int qk_debug_tap(qk_engine *e, int which, int rx, double *out_host, int cap);
 /* Statistics (debug): speculation passes the AGC kernel has run for receiver rx since creation. */
 long long qk_debug_agc_passes(qk_engine *e, int rx);

@@ -1216,6 +1216,72 @@ int qko_buffer2chan(qko_b2c *b, double *samp1, int count1, double *samp2, int co
     b->nbuf2 -= nout; memmove(b->buf2, b->buf2 + nout, (size_t)b->nbuf2 * sizeof(double));
     return nout;
 }
+/* quisk_process_samples with a second channel (quisk.c:2403-2601): receiver `a` is bank 0, receiver `b` the second channel
+ * (split RX/TX: the same mode and filter, tuned to the transmit frequency, quisk.c:2410-2418; or the sub-receiver of
+ * multirx_play_channel, quisk.c:2463-2472).  Both are mixed, decimated and demodulated on the same input; Buffer2Chan
+ * equalises the counts at the decimated rate; the pair goes through cFracDecim and the play-rate interpolators -- the
+ * statics of quisk_process_samples, i.e. a's -- and Agc1 (a's) runs on the left channel, Agc2 (the pair's) on the right,
+ * each as a mono process_agc (quisk.c:2563-2572); then the squelch per channel (quisk.c:2585-2601).
+ * method 1: left = a, right = b; 2: left = b, right = a; 3: both = b; 4: both = a.  x: n input samples, overwritten by the
+ * stereo block; pre (optional, same capacity): the pair in front of the AGCs.  Returns the count. */
+void qko_pair_init(qko_pair *p) { memset(p, 0, sizeof *p); qko_agc_init(&p->agc2, 0.7, 0); }
+void qko_pair_free(qko_pair *p) { qko_agc_free(&p->agc2); free(p->xb); free(p->ab); free(p->ch); p->xb = NULL; p->ab = NULL; p->ch = NULL; }
+qko_pair *qko_pair_new(void) { qko_pair *p = (qko_pair *)malloc(sizeof *p); qko_pair_init(p); return p; }
+void qko_pair_delete(qko_pair *p) { if (p) { qko_pair_free(p); free(p); } }
+void qko_pair_reset_fifos(qko_pair *p) { p->b2c.nbuf1 = p->b2c.nbuf2 = 0; }      /* Buffer2Chan(NULL, 0, NULL, 0), quisk.c:2227-2231 */
+int qko_rx_pair_process(qko_rx *a, qko_rx *b, qko_pair *p, qko_cd *x, int n, int method, qko_cd *pre)
+{
+    int i, na, nb, m, sq_l, sq_r, fm;
+    if (n <= 0) return n;
+    if (n * 2 > p->cap) {
+        free(p->xb); free(p->ab); free(p->ch);
+        p->cap = n * 2 + 2 * QKO_B2C_SIZE;
+        p->xb = (qko_cd *)malloc((size_t)p->cap * sizeof(qko_cd));
+        p->ab = (double *)malloc((size_t)p->cap * sizeof(double));
+        p->ch = (qko_cd *)malloc((size_t)p->cap * sizeof(qko_cd));
+    }
+    if (p->cap > a->naudio) {
+        free(a->audio);
+        a->naudio = p->cap;
+        a->audio = (double *)malloc((size_t)a->naudio * sizeof(double));
+    }
+    memcpy(p->xb, x, (size_t)n * sizeof(qko_cd));                 /* orig_cSamples, quisk.c:2226 */
+    qko_rx_mix(a, x, n);
+    na = qko_rx_decimate(a, x, n);
+    na = qko_rx_demodulate(a, x, a->audio, na);
+    qko_rx_mix(b, p->xb, n);                                      /* quisk.c:2411-2418 */
+    nb = qko_rx_decimate(b, p->xb, n);
+    nb = qko_rx_demodulate(b, p->xb, p->ab, nb);
+    m = qko_buffer2chan(&p->b2c, a->audio, na, p->ab, nb);        /* quisk.c:2419 */
+    for (i = 0; i < m; i++) {
+        const double l = (method == 1 || method == 4) ? a->audio[i] : p->ab[i];
+        const double r = (method == 2 || method == 4) ? a->audio[i] : p->ab[i];
+        x[i] = l + I * r;
+    }
+    sq_l = (method == 1 || method == 4) ? a->sq_active : b->sq_active;
+    sq_r = (method == 2 || method == 4) ? a->sq_active : b->sq_active;
+    if (a->decim_srate != 48000) {                                /* quisk.c:2528-2532 */
+        m = qko_fracdecim(&a->frac, x, m, a->decim_srate / 48000.0);
+        a->decim_srate = 48000;
+    }
+    switch (a->playback_rate / 48000) {                           /* quisk.c:2535-2553 */
+    case 8: m = qko_cinterp2hb45(x, m, &a->play_hb[0]); m = qko_cinterp2hb45(x, m, &a->play_hb[1]);
+            m = qko_cinterp2hb45(x, m, &a->play_hb[2]); break;
+    case 4: m = qko_cinterp2hb45(x, m, &a->play_hb[0]); m = qko_cinterp2hb45(x, m, &a->play_hb[1]); break;
+    case 2: m = qko_cinterp2hb45(x, m, &a->play_hb[0]); break;
+    default: break;
+    }
+    if (pre) memcpy(pre, x, (size_t)m * sizeof(qko_cd));
+    fm = a->mode == QKO_FM || a->mode == QKO_DGT_FM;               /* rxMode, quisk.c:2088 */
+    for (i = 0; i < m; i++) { p->ch[i] = cimag(x[i]); x[i] = creal(x[i]); }        /* quisk.c:2564-2567 */
+    qko_agc_process(&a->agc, x, m, 0, a->playback_rate, a->release_gain, a->release_time, fm);
+    qko_agc_process(&p->agc2, p->ch, m, 0, a->playback_rate, a->release_gain, a->release_time, fm);
+    for (i = 0; i < m; i++) x[i] = creal(x[i]) + I * creal(p->ch[i]);
+    if (a->kill_audio || (sq_l && sq_r)) { for (i = 0; i < m; i++) x[i] = 0; }     /* quisk.c:2585-2601 */
+    else if (sq_r) { for (i = 0; i < m; i++) x[i] = creal(x[i]); }
+    else if (sq_l) { for (i = 0; i < m; i++) x[i] = I * cimag(x[i]); }
+    return m;
+}
 double qko_keyup_envelope(double env, qko_cd *x, int n, int playback_rate)
 {   /* quisk.c:2602-2612; returns the new keyupEnvelope */
     int i;

@@ -150,6 +150,14 @@ int qko_graph_release(qko_graph *g, double zoom, double deltaf, double *out, dou
 typedef struct { int nbuf1, nbuf2; double buf1[QKO_B2C_SIZE], buf2[QKO_B2C_SIZE]; } qko_b2c;
 int qko_buffer2chan(qko_b2c *b, double *samp1, int count1, double *samp2, int count2);
 double qko_keyup_envelope(double env, qko_cd *x, int n, int playback_rate);
+/* quisk_process_samples with a second channel (split RX/TX, multirx play; quisk.c:2410-2494, 2528-2601): see qk_oracle.c */
+typedef struct { qko_b2c b2c; qko_agc agc2; qko_cd *xb, *ch; double *ab; int cap; } qko_pair;
+void qko_pair_init(qko_pair *p);
+void qko_pair_free(qko_pair *p);
+qko_pair *qko_pair_new(void);
+void qko_pair_delete(qko_pair *p);
+void qko_pair_reset_fifos(qko_pair *p);
+int qko_rx_pair_process(qko_rx *a, qko_rx *b, qko_pair *p, qko_cd *x, int n, int method, qko_cd *pre);
 
 /* get_multirx_graph (quisk.c:4468-4530): 8 * data_width samples (overwritten) -> data_width dB values */
 void qko_multirx_graph(qko_cd *samples, int data_width, double *out);

@@ -68,6 +68,8 @@ class _State:
         self.vfo_screen = self.vfo_audio = 0
         self.scan = None               # change_scan's arguments while a scan is on
         self.split_rxtx = 0
+        self.rit_freq = 0
+        self.nrx = 0
         self.play_method = 0
         self.play_channel = -1
         self.f0 = None                 # filter slot 0 as last set: (fi, fq, bw, start_offset)
@@ -97,7 +99,8 @@ def record_app(app, conf, data_width, graph_width, fft_size, multirx_data_width,
     s.multirx_data_width, s.rate = int(multirx_data_width), int(rate)
     nrx = int(getattr(conf, "quisk_amd_receivers", 1 + QUISK_MAX_RECEIVERS))
     try:
-        s.eng = _eng.Engine(s.rate, n_receivers=nrx, playback_rate=int(getattr(conf, "playback_rate", 48000)),
+        s.nrx = nrx                                     # the receivers the caller sees; one more is kept for the split RX/TX partner
+        s.eng = _eng.Engine(s.rate, n_receivers=nrx + 1, playback_rate=int(getattr(conf, "playback_rate", 48000)),
                             max_block=SAMP_BUFFER_SIZE, fft_size=s.fft_size, data_width=s.data_width,
                             device=int(getattr(conf, "quisk_amd_device", 0)),
                             max_filter_taps=int(getattr(conf, "quisk_amd_max_filter_taps", 0)))
@@ -223,7 +226,7 @@ def set_filters(filterI, filterQ, bw, start_offset, nFilter):
         targets = [0]
         s.f0 = (fi, fq, int(bw), int(start_offset))
     elif nFilter == 1:
-        targets = list(range(1, s.eng.n_receivers))
+        targets = list(range(1, s.nrx))
     else:
         targets = []                                   # slot 2 feeds the external digital-mode path (quisk.c:2515): off the path
     try:
@@ -246,7 +249,7 @@ def set_multirx_mode(index, mode):
     """quisk.c:4426-4436: silently ignored beyond QUISK_MAX_RECEIVERS."""
     s = _st()
     index = int(index)
-    if index < QUISK_MAX_RECEIVERS and 1 + index < s.eng.n_receivers:
+    if index < QUISK_MAX_RECEIVERS and 1 + index < s.nrx:
         try:
             s.eng.set_mode(1 + index, int(mode))
         except Exception as exc:
@@ -257,7 +260,7 @@ def set_multirx_freq(index, freq):
     """quisk.c:4438-4448."""
     s = _st()
     index = int(index)
-    if index < QUISK_MAX_RECEIVERS and 1 + index < s.eng.n_receivers:
+    if index < QUISK_MAX_RECEIVERS and 1 + index < s.nrx:
         s.eng.set_tune(1 + index, int(freq))
 
 
@@ -400,19 +403,18 @@ def set_noise_blanker(level):
 
 def _update_route(s):
     """Which receiver is heard beside receiver 0, and in which ear (quisk.c:2410-2494), as csrc/quisk_module.c does it: split
-    RX/TX demodulates the stream a second time at the transmit offset with receiver 0's mode and filter on the LAST receiver of
-    the engine; the multirx play channel is sub-receiver 1 + index."""
+    RX/TX demodulates the stream a second time at the transmit offset + RIT with receiver 0's mode and filter (quisk.c:2411,
+    2417-2418) on a receiver of the engine kept for that alone (index nrx); the multirx play channel is sub-receiver 1 + index."""
     method, partner = 0, 0
-    nrx = s.eng.n_receivers
-    if 1 <= s.split_rxtx <= 4 and nrx >= 2:
-        partner = nrx - 1
+    if 1 <= s.split_rxtx <= 4:
+        partner = s.nrx
         rx_left = (s.tx_tune < s.rx_tune) if s.split_rxtx == 1 else (s.tx_tune >= s.rx_tune)       # quisk.c:2424, 2438
-        method = 0 if s.split_rxtx == 3 else 3 if s.split_rxtx == 4 else (1 if rx_left else 2)
+        method = 4 if s.split_rxtx == 3 else 3 if s.split_rxtx == 4 else (1 if rx_left else 2)
         s.eng.set_mode(partner, s.rx_mode)
-        s.eng.set_tune(partner, s.tx_tune)
+        s.eng.set_tune(partner, s.tx_tune + s.rit_freq)
         if s.f0 is not None:
             s.eng.set_filters(partner, *s.f0)
-    elif s.play_channel >= 0 and 1 + s.play_channel < nrx:
+    elif s.play_channel >= 0 and 1 + s.play_channel < s.nrx:
         partner = 1 + s.play_channel
         method = 1 if s.play_method == 1 else 2 if s.play_method == 2 else 3                        # quisk.c:2474-2493
     s.eng.set_stereo_route(0, partner, method)
@@ -464,6 +466,9 @@ def set_sidetone(ctrl, volume, rit, keyup):
     """quisk.c:4331-4346 ("idii"): of the four values the receive path uses rit_freq."""
     if _S is not None and _S.eng is not None:
         _S.eng.set_rit_freq(int(rit))
+        _S.rit_freq = int(rit)
+        if _S.split_rxtx:
+            _update_route(_S)                           # the second channel is tuned to tx + rit (quisk.c:2411)
 
 
 def _apply_tune_and_scan(s):

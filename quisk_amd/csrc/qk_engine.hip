@@ -39,6 +39,8 @@ constexpr int DEFAULT_TAP_CAP = 1024;
 constexpr int FFT_BATCH = 8;          // display-spectrum frames per four-step launch
 constexpr int FFT_GROUPS = 2;         // frame groups of the four-step row pass, each with its own partial average
 constexpr int EV_POOL = 2048;
+constexpr int QK_MAX_ROUTES = 4;       // stereo routes (split RX/TX, multirx play) per engine: two AGC slots each behind the receivers'
+constexpr int AGC_SKIP_CLASS = 7;      // an AGC class index that never has samples: a receiver whose AGC runs in a route's slot
 
 enum StageKind { ST_FIR, ST_INTERP, ST_HBINT, ST_RESAMP, ST_RXF, ST_FMDISC, ST_IIR, ST_FRAC };
 enum ChainClass { CL_SSB = 0, CL_CW, CL_AM, CL_FM, CL_DGTW, CL_DGTIQ, CL_COUNT };    // CL_DGTW: DGT-U/L filtered at the decimated rate;
@@ -200,8 +202,17 @@ struct qk_engine {
     double *d_ssb_carry = nullptr; int *d_ssb_state = nullptr, *d_bw = nullptr, *d_notch_on = nullptr;
     NotchState *d_notch = nullptr; std::vector<int> notch_on; bool any_notch = false;
     // second-receiver routing (quisk.c:2410-2494) and Buffer2Chan's FIFOs (quisk.c:1452-1487), one per routed receiver
-    struct Route { int rx = 0, partner = 0, method = 0, nbuf_a = 0, nbuf_b = 0, cur = 0; double *fifo[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; };
-    std::vector<Route> routes; double2 *d_route_tmp = nullptr; int route_cap = 0;
+    // A route owns the part of the chain that the reference runs on the PAIR (quisk.c:2419-2572): Buffer2Chan's FIFOs at the
+    // decimated rate, then -- `tail`, two rows: 0 = left, 1 = right -- cFracDecim, the play-rate interpolators and the two AGCs.
+    // AGC slot `slot` (left) holds Agc1 while the route is live (the receiver's own state, moved in and out), slot + 1 is Agc2.
+    struct Route { int rx = 0, partner = 0, method = 0, nbuf_a = 0, nbuf_b = 0, cur = 0; double *fifo[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+                   Chain tail; int slot = 0; bool live = false;
+                   // mono behind a stretch of stereo: the route runs on (k_route_drain_apply) until the two channels' filter
+                   // histories and Agc1's ring hold the same samples again -- `drain` output samples from the switch -- and
+                   // only then hands the left channel's objects back to the receiver's class
+                   bool stereo = false; long long drain = 0;
+                   double *d_agc2_ring = nullptr; };     // Agc2's delay ring between two stretches of stereo
+    std::vector<Route> routes; int route_cap = 0; int *d_agc_cls = nullptr, *d_zero2 = nullptr;
     // key-up envelope (quisk.c:2602-2612): keyupEnvelope and the pinned per-block factors the ramp kernel reads
     double keyup_env = 1.0; double *h_keyup = nullptr; int *h_keyup_counts = nullptr; int keyup_cap = 0;
     hipEvent_t ev_keyup = nullptr; bool keyup_used = false;
@@ -392,10 +403,10 @@ static void free_chain(Chain &c)
     c = Chain();
 }
 
-static int alloc_chain_streams(qk_engine *e, Chain &c)
+static int alloc_chain_streams(qk_engine *e, Chain &c, int rows = -1)
 {
     for (auto &s : c.streams) {
-        size_t bytes = (size_t)e->nrx * s.rx_stride() * sizeof(double);
+        size_t bytes = (size_t)(rows > 0 ? rows : e->nrx) * s.rx_stride() * sizeof(double);
         HIPCHECK(hipMalloc(&s.d, bytes));
         HIPCHECK(hipMemsetAsync(s.d, 0, bytes, e->stream));
     }
@@ -597,8 +608,17 @@ static int build_class(qk_engine *e, int cl)
     return QK_OK;
 }
 
+// the class whose play stream a receiver's AGC reads: its chain class, or none while a live route runs its AGC
+static int upload_agc_cls(qk_engine *e)
+{
+    std::vector<int> ac(e->cls);
+    for (auto &r : e->routes) if (r.live) ac[r.rx] = AGC_SKIP_CLASS;
+    HIPCHECK(hipMemcpy(e->d_agc_cls, ac.data(), sizeof(int) * e->nrx, hipMemcpyHostToDevice));
+    return QK_OK;
+}
 static int upload_members(qk_engine *e)
 {
+    { int rca = upload_agc_cls(e); if (rca != QK_OK) return rca; }
     HIPCHECK(hipMemcpyAsync(e->d_cls, e->cls.data(), sizeof(int) * e->nrx, hipMemcpyHostToDevice, e->stream));
     for (int cl = 0; cl < CL_COUNT; cl++) e->cls_chain[cl].members.clear();
     for (int r = 0; r < e->nrx; r++) e->cls_chain[e->cls[r]].members.push_back(r);
@@ -865,29 +885,37 @@ static int init_receivers(qk_engine *e)
     HIPCHECK(hipMalloc(&e->d_ntaps, nrx * sizeof(int)));
     HIPCHECK(hipMemset(e->d_ntaps, 0, nrx * sizeof(int)));
     HIPCHECK(hipMalloc(&e->d_cls, nrx * sizeof(int)));
-    HIPCHECK(hipMalloc(&e->d_mode, nrx * sizeof(int)));
+    const size_t nslots = nrx + 2 * QK_MAX_ROUTES;               // the receivers' AGCs, then Agc1 / Agc2 of every stereo route
+    HIPCHECK(hipMalloc(&e->d_mode, nslots * sizeof(int)));
+    HIPCHECK(hipMemset(e->d_mode, 0, nslots * sizeof(int)));
     HIPCHECK(hipMemcpy(e->d_mode, e->mode.data(), nrx * sizeof(int), hipMemcpyHostToDevice));
-    std::vector<double> rel(nrx, 80.0);                          // agcReleaseGain, quisk.c:145
-    HIPCHECK(hipMalloc(&e->d_release_gain, nrx * sizeof(double)));
-    HIPCHECK(hipMemcpy(e->d_release_gain, rel.data(), nrx * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&e->d_agc_cls, nrx * sizeof(int)));
+    HIPCHECK(hipMalloc(&e->d_zero2, 2 * sizeof(int)));
+    HIPCHECK(hipMemset(e->d_zero2, 0, 2 * sizeof(int)));
+    std::vector<double> rel(nslots, 80.0);                       // agcReleaseGain, quisk.c:145
+    HIPCHECK(hipMalloc(&e->d_release_gain, nslots * sizeof(double)));
+    HIPCHECK(hipMemcpy(e->d_release_gain, rel.data(), nslots * sizeof(double), hipMemcpyHostToDevice));
     // AGC state as process_agc initialises it (quisk.c:2038-2044)
-    std::vector<AgcState> ag(nrx);
+    std::vector<AgcState> ag(nslots);
     for (auto &a : ag) { a.themax = 1.0; a.gain = 100; a.delta = 0; a.target_gain = 100; a.index_read = a.index_start = a.is_clipping = a.pad = 0; }
-    HIPCHECK(hipMalloc(&e->d_agc, nrx * sizeof(AgcState)));
-    HIPCHECK(hipMemcpy(e->d_agc, ag.data(), nrx * sizeof(AgcState), hipMemcpyHostToDevice));
-    HIPCHECK(hipMalloc(&e->d_agc_started, nrx * sizeof(int)));
-    HIPCHECK(hipMemset(e->d_agc_started, 0, nrx * sizeof(int)));
-    e->agc_started.assign(nrx, 0);
+    HIPCHECK(hipMalloc(&e->d_agc, nslots * sizeof(AgcState)));
+    HIPCHECK(hipMemcpy(e->d_agc, ag.data(), nslots * sizeof(AgcState), hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&e->d_agc_started, nslots * sizeof(int)));
+    HIPCHECK(hipMemset(e->d_agc_started, 0, nslots * sizeof(int)));
+    e->agc_started.assign(nslots, 0);
     HIPCHECK(hipHostMalloc(&e->h_agc_abort, sizeof(int), hipHostMallocMapped));
     *e->h_agc_abort = 0;
     HIPCHECK(hipHostGetDevicePointer((void **)&e->d_agc_abort, e->h_agc_abort, 0));
     // output: the audio of one block at the play rate
-    const long long per_block = (long long)cfg.max_block * cfg.playback_rate / cfg.sample_rate + 64;
+    // (a stereo route's block can be longer than a receiver's by what its FIFOs held: BUF2CHAN_SIZE at the most, quisk.c:1452)
+    e->route_cap = 12000;
+    const long long per_block = (long long)cfg.max_block * cfg.playback_rate / cfg.sample_rate + 64 +
+                                (long long)e->route_cap * (cfg.playback_rate / 48000) * 5 / 4;
     if (per_block > (1LL << 26)) return fail(QK_ERANGE, "max_block gives more than 2^26 audio samples per block (k_agc_gain tile index)");
     e->out_stride = (size_t)((per_block + 63) & ~63LL);
     e->gain_stride = (int)e->out_stride;
-    HIPCHECK(hipMalloc(&e->d_out, nrx * e->out_stride * sizeof(double2)));
-    HIPCHECK(hipMemset(e->d_out, 0, nrx * e->out_stride * sizeof(double2)));
+    HIPCHECK(hipMalloc(&e->d_out, nslots * e->out_stride * sizeof(double2)));
+    HIPCHECK(hipMemset(e->d_out, 0, nslots * e->out_stride * sizeof(double2)));
     HIPCHECK(hipMalloc(&e->d_ssb_carry, nrx * SSQ_N * sizeof(double)));
     HIPCHECK(hipMemset(e->d_ssb_carry, 0, nrx * SSQ_N * sizeof(double)));
     HIPCHECK(hipMalloc(&e->d_ssb_state, nrx * 4 * sizeof(int)));
@@ -897,12 +925,11 @@ static int init_receivers(qk_engine *e)
     HIPCHECK(hipMalloc(&e->d_notch_on, nrx * sizeof(int)));
     HIPCHECK(hipMemset(e->d_notch_on, 0, nrx * sizeof(int)));
     e->notch_on.assign(nrx, 0);
-    e->route_cap = 12000 * (cfg.playback_rate / 48000);                  // BUF2CHAN_SIZE (quisk.c:1452) at the play rate
     e->keyup_cap = (int)(cfg.playback_rate * 5e-3) + 8;
     HIPCHECK(hipHostMalloc(&e->h_keyup, sizeof(double) * e->keyup_cap, hipHostMallocMapped));
     HIPCHECK(hipHostMalloc(&e->h_keyup_counts, sizeof(int) * nrx, hipHostMallocMapped));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_keyup, sync_event_flags()));
-    HIPCHECK(hipMalloc(&e->d_gains, nrx * e->gain_stride * sizeof(double)));
+    HIPCHECK(hipMalloc(&e->d_gains, nslots * e->gain_stride * sizeof(double)));
     HIPCHECK(hipMalloc(&e->d_agc_mag, nrx * e->gain_stride * sizeof(double)));
     if (e->apply_stream) {
         HIPCHECK(hipMalloc(&e->d_gains2, nrx * e->gain_stride * sizeof(double)));
@@ -1700,24 +1727,9 @@ static const double2 *condition_input(qk_engine *e, const double2 *x, int n)
     return x;
 }
 
-// Second-receiver routing and the key-up envelope (quisk.c:2410-2494, 2602-2612), queued behind k_agc_apply.
+// The key-up envelope (quisk.c:2602-2612), queued behind k_agc_apply (and the routes' k_route_combine).
 static int output_stage(qk_engine *e, hipStream_t st)
 {
-    for (auto &r : e->routes) {
-        if (r.method <= 0) continue;
-        const int ca = e->out_count[r.rx], cb = e->out_count[r.partner];
-        if (ca + r.nbuf_a >= e->route_cap || cb + r.nbuf_b >= e->route_cap) r.nbuf_a = r.nbuf_b = 0;   // overflow: drop what waits (quisk.c:1465-1469)
-        const int ta = r.nbuf_a + ca, tb = r.nbuf_b + cb, nout = std::min(ta, tb);
-        RouteArgs a{e->d_out, (long long)e->out_stride, r.rx, r.partner, r.method, r.fifo[r.cur][0], r.fifo[r.cur][1],
-                    r.fifo[r.cur ^ 1][0], r.fifo[r.cur ^ 1][1], r.nbuf_a, r.nbuf_b, ca, cb, nout, e->d_route_tmp};
-        const int span = std::max(ta, tb);
-        if (span > 0) {
-            hipLaunchKernelGGL(k_route_mix, dim3((span + 255) / 256), dim3(256), 0, st, a);
-            if (nout > 0) hipLaunchKernelGGL(k_route_store, dim3((nout + 255) / 256), dim3(256), 0, st, a);
-        }
-        r.nbuf_a = ta - nout; r.nbuf_b = tb - nout; r.cur ^= 1;
-        e->out_count[r.rx] = nout;
-    }
     if (e->keyup_env < 1.0) {
         if (e->keyup_used) HIPCHECK(hipEventSynchronize(e->ev_keyup));      // the previous block's ramp kernel still reads the pinned arrays
         int m_max = 0;
@@ -1741,6 +1753,14 @@ static int output_stage(qk_engine *e, hipStream_t st)
     return QK_OK;
 }
 
+static int route_transfer(qk_engine *e, qk_engine::Route &r, bool to_live);
+static int sync_all(qk_engine *e)
+{
+    HIPCHECK(hipStreamSynchronize(e->fe_stream)); HIPCHECK(hipStreamSynchronize(e->stream));
+    HIPCHECK(hipStreamSynchronize(e->agc_stream));
+    if (e->apply_stream) HIPCHECK(hipStreamSynchronize(e->apply_stream));
+    return QK_OK;
+}
 static int process_device(qk_engine *e, const double2 *x, int n)
 {
     if (n < 0 || n > e->cfg.max_block) return fail(QK_ERANGE, "block larger than max_block");
@@ -1754,6 +1774,16 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         e->stats.samples_in += n;
         e->stats.blocks += 1;
         return QK_OK;
+    }
+    for (auto &r : e->routes) {
+        // a route that has been mono for long enough: both channels carry the same samples again, the receiver's class takes over
+        if (!r.live || r.stereo || r.drain > 0) continue;
+        int rct = sync_all(e);
+        if (rct == QK_OK) rct = route_transfer(e, r, false);
+        if (rct != QK_OK) return rct;
+        r.live = false;
+        rct = upload_agc_cls(e);
+        if (rct != QK_OK) return rct;
     }
     const int S = e->S;
     Chain &F = e->front;
@@ -1875,6 +1905,30 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         HIPCHECK(hipEventRecord(e->ev_lane[k - 1], lanes[k]));
         HIPCHECK(hipStreamWaitEvent(e->stream, e->ev_lane[k - 1], 0));
     }
+    // ---- stereo routes: the two detected streams, count-equalised, become one pair that runs its own tail chain ----
+    for (auto &r : e->routes) {
+        if (!r.live) continue;
+        Chain &ca = e->cls_chain[e->cls[r.rx]], &cb = e->cls_chain[e->cls[r.partner]];
+        const Stream &sa = ca.streams[ca.aud], &sb = r.stereo ? cb.streams[cb.aud] : sa;
+        const int na = sa.n, nb = sb.n;
+        if (na + r.nbuf_a >= e->route_cap || nb + r.nbuf_b >= e->route_cap) r.nbuf_a = r.nbuf_b = 0;   // overflow: drop what waits (quisk.c:1465-1469)
+        const int ta = r.nbuf_a + na, tb = r.nbuf_b + nb, nout = std::min(ta, tb);
+        Chain &t = r.tail;
+        std::swap(t.streams[t.play].d, t.play_alt);
+        if (nout > t.streams[0].cap) return fail(QK_ERANGE, "internal: a route's block exceeds its pair stream");
+        RouteArgs a{sa.view(), sb.view(), r.rx, r.stereo ? r.partner : r.rx, r.stereo ? r.method : 4, r.fifo[r.cur][0], r.fifo[r.cur][1],
+                    r.fifo[r.cur ^ 1][0], r.fifo[r.cur ^ 1][1], r.nbuf_a, r.nbuf_b, na, nb, nout, t.streams[0].view()};
+        const int span = std::max(ta, tb);
+        if (span > 0) hipLaunchKernelGGL(k_route_pair, dim3((span + 255) / 256), dim3(256), 0, e->stream, a);
+        r.nbuf_a = ta - nout; r.nbuf_b = tb - nout; r.cur ^= 1;
+        t.streams[0].n = nout;
+        rc = run_chain(e, t, t.streams[0], nullptr, 2, e->stream);
+        if (rc != QK_OK) return rc;
+        t.n_out = t.streams[t.play].n;
+        if (t.n_out == 0) std::swap(t.streams[t.play].d, t.play_alt);
+        if (t.n_out > (int)e->out_stride) return fail(QK_ERANGE, "internal: audio block exceeds the output stride");
+        e->out_count[r.rx] = t.n_out;
+    }
     HIPCHECK(hipEventRecord(e->ev_chain, e->stream));
     HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_chain, 0));
     if (fe_writes) {
@@ -1901,7 +1955,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         }
         e->last_m_max = m_max;
         if (m_max > 0) {
-            a.cls = e->d_cls; a.gains = (e->apply_stream && par) ? e->d_gains2 : e->d_gains; a.gain_stride = e->gain_stride;
+            a.cls = e->d_agc_cls; a.gains = (e->apply_stream && par) ? e->d_gains2 : e->d_gains; a.gain_stride = e->gain_stride;
             a.buf_size = rate * 15 / 1000; a.n_rx = e->nrx;
             a.ceiling = 0.7 * QK_CLIP32;                                         // Agc1 max_out, quisk.c:2181
             a.time_release = 1.0 - exp(-1.0 / rate / e->agc_release_time);       // quisk.c:2045
@@ -1942,6 +1996,41 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             }
         }
     }
+    for (auto &r : e->routes) {
+        // ---- a route's two AGCs: Agc1 on the left channel, Agc2 on the right (quisk.c:2563-2572), each a mono process_agc;
+        //      then both channels into the receiver's output row, the squelch per channel (quisk.c:2585-2601) ----
+        Chain &t = r.tail;
+        if (!r.live || t.n_out <= 0) continue;
+        const int rate = e->cfg.playback_rate, m = t.n_out;
+        AgcArgs a{};
+        a.in_c[0] = t.streams[t.play].view(); a.mag_c[0] = a.in_c[0]; a.n_c[0] = m;
+        a.cls = e->d_zero2; a.gains = e->d_gains + (size_t)r.slot * e->gain_stride; a.gain_stride = e->gain_stride;
+        a.buf_size = rate * 15 / 1000; a.n_rx = 2;
+        a.ceiling = 0.7 * QK_CLIP32; a.time_release = 1.0 - exp(-1.0 / rate / e->agc_release_time);
+        a.release_gain = e->d_release_gain + r.slot; a.mode = e->d_mode + r.slot; a.state = e->d_agc + r.slot;
+        a.out = e->d_out + (size_t)r.slot * e->out_stride; a.out_stride = (long long)e->out_stride;
+        a.started = e->d_agc_started + r.slot; a.abort_flag = e->d_agc_abort;
+        a.mute = nullptr; a.kill = 0;
+        hipStream_t st = agc_ev_stream;
+        if (!r.stereo) {
+            hipLaunchKernelGGL(k_agc_gain, dim3(1), dim3(192), 0, st, a);
+            DrainArgs da{a.in_c[0], a.gains, a.buf_size, m, a.started, e->d_out + (size_t)r.rx * e->out_stride, e->d_sq_flag + par * e->nrx + r.rx,
+                         e->kill_audio};
+            hipLaunchKernelGGL(k_route_drain_apply, dim3((m + 255) / 256), dim3(256), 0, st, da);
+            if (!e->agc_started[r.slot]) hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_agc_started + r.slot), 1, 1, st);
+            r.drain -= m;
+            continue;
+        }
+        hipLaunchKernelGGL(k_agc_gain, dim3(2), dim3(192), 0, st, a);
+        hipLaunchKernelGGL(k_agc_apply, grid1(m, 1, 2), dim3(256), 0, st, a);
+        const int src_l = (r.method == 1 || r.method == 4) ? r.rx : r.partner, src_r = (r.method == 2 || r.method == 4) ? r.rx : r.partner;
+        const int *fl = e->d_sq_flag + par * e->nrx;
+        hipLaunchKernelGGL(k_route_combine, dim3((m + 255) / 256), dim3(256), 0, st, a.out, a.out + e->out_stride,
+                           e->d_out + (size_t)r.rx * e->out_stride, m, fl + src_l, fl + src_r, e->kill_audio);
+        for (int ch = 0; ch < 2; ch++)
+            if (!e->agc_started[r.slot + ch])
+                hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_agc_started + r.slot + ch), 1, 1, st);
+    }
     {   // ---- output stage behind the AGC, on the stream that wrote the output rows ----
         int rco = output_stage(e, agc_ev_stream);
         if (rco != QK_OK) return rco;
@@ -1976,6 +2065,23 @@ static int process_device(qk_engine *e, const double2 *x, int n)
                 }
             }
         }
+        for (auto &r : e->routes) {
+            if (!r.live) continue;
+            Chain &t = r.tail;
+            TailArgs tb{}; tb.count = 0; tb.rx_list = nullptr;
+            add_tails(tb, t, t.play);
+            Stream &play = t.streams[t.play];
+            if (play.n > 0 && tb.count < QK_MAX_TAILS)
+                tb.t[tb.count++] = TailDesc{play.d, play.rx_stride(), play.hist + play.cap, play.planes, play.hist, play.n, t.play_alt};
+            if (tb.count) hipLaunchKernelGGL(k_save_tails, dim3(tb.count, 2, 2), dim3(256), 0, e->stream, tb);
+            if (t.n_out > 0)
+                for (int ch = 0; ch < (r.stereo ? 2 : 1); ch++) {        // a first process_agc call does not store its block (quisk.c:2033-2050)
+                    if (e->agc_started[r.slot + ch]) continue;
+                    hipMemsetAsync(t.play_alt + (long long)ch * play.rx_stride(), 0, sizeof(double) * play.hist, e->stream);
+                    if (!r.stereo) hipMemsetAsync(t.play_alt + play.rx_stride(), 0, sizeof(double) * play.hist, e->stream);
+                    e->agc_started[r.slot + ch] = 1;
+                }
+        }
         e->agc_pending = true;
     }
     HIPCHECK(hipGetLastError());
@@ -1987,6 +2093,10 @@ static int process_device(qk_engine *e, const double2 *x, int n)
 
 // =================================================================================== C ABI
 extern "C" {
+
+static int routes_refresh(qk_engine *e);
+static int route_sync_params(qk_engine *e);
+static int route_stereo(qk_engine *e, qk_engine::Route &r, bool on);
 
 const char *qk_last_error(void) { return g_err.c_str(); }
 const char *qk_version(void) { return "quisk_amd 0.1 (gfx950)"; }
@@ -2044,7 +2154,9 @@ void qk_destroy(qk_engine *e)
     if (e->h_keyup) hipHostFree(e->h_keyup);
     if (e->h_keyup_counts) hipHostFree(e->h_keyup_counts);
     if (e->ev_keyup) hipEventDestroy(e->ev_keyup);
-    if (e->d_route_tmp) hipFree(e->d_route_tmp);
+    for (auto &r : e->routes) { free_chain(r.tail); if (r.d_agc2_ring) hipFree(r.d_agc2_ring); }
+    if (e->d_agc_cls) hipFree(e->d_agc_cls);
+    if (e->d_zero2) hipFree(e->d_zero2);
     for (void *p : {(void *)e->d_ssb_carry, (void *)e->d_ssb_state, (void *)e->d_bw, (void *)e->d_notch_on, (void *)e->d_notch}) if (p) hipFree(p);
     for (auto &r : e->routes) for (auto &q : r.fifo) for (double *p : q) if (p) hipFree(p);
     for (double *p : e->d_obj) if (p) hipFree(p);
@@ -2109,12 +2221,23 @@ int qk_set_mode(qk_engine *e, int rx, int mode)
     { int rcn = upload_ntaps(e, rx); if (rcn != QK_OK) return rcn; }
     for (int b = 0; b < 2; b++) HIPCHECK(hipMemset(e->d_sq_flag + b * e->nrx + rx, 0, sizeof(int)));     // squelch_active = 0, quisk.c:1777
     if (e->cls[rx] != cl) {
+        // (a live route keeps the objects behind the detector -- cFracDecim, HalfBand7..9, the AGCs belong to no mode -- whatever
+        // class the receiver is in; only DGT-IQ, stereo by itself, takes them back at once)
+        if (cl == CL_DGTIQ)
+            for (auto &r : e->routes) {
+                if (!r.live || r.rx != rx) continue;
+                int rct = r.stereo ? route_stereo(e, r, false) : QK_OK;
+                if (rct == QK_OK) rct = route_transfer(e, r, false);
+                if (rct != QK_OK) return rct;
+                r.live = false; r.drain = 0;
+            }
         const int from = e->cls[rx];
         e->cls[rx] = cl;
         int rcm = upload_members(e);
-        return rcm != QK_OK ? rcm : migrate_receiver(e, rx, from, cl);
+        if (rcm == QK_OK) rcm = migrate_receiver(e, rx, from, cl);
+        if (rcm != QK_OK) return rcm;
     }
-    return QK_OK;
+    return routes_refresh(e);
 }
 
 int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int n, int bandwidth, int start_offset)
@@ -2237,7 +2360,7 @@ int qk_set_agc(qk_engine *e, int rx, double release_gain)
     ENGINE_ENTER(e); RX_CHECK(e, rx);
     SYNC_ALL(e);
     HIPCHECK(hipMemcpy(e->d_release_gain + rx, &release_gain, sizeof(double), hipMemcpyHostToDevice));
-    return QK_OK;
+    return route_sync_params(e);
 }
 
 int qk_set_agc_release_time(qk_engine *e, double seconds)
@@ -2543,25 +2666,184 @@ int qk_is_squelch(qk_engine *e, int freq)
     return (meter == 0 || meter < e->squelch_level) ? 1 : 0;
 }
 
+// ---- stereo routes ----
+static int build_route_tail(qk_engine *e, qk_engine::Route &r)
+{
+    Chain &t = r.tail;
+    const Stream &dec = e->front.streams[e->front.aud];
+    const int cap_in = dec.cap + e->route_cap + 64;
+    ChainBuilder b(t, cap_in);
+    b.cur = b.new_stream(1, cap_in);                                   // stream 0: the pair (row 0 = left, row 1 = right)
+    b.cur_cap = cap_in;
+    if (e->decim_srate != 48000) {                                     // quisk.c:2528-2532
+        b.need_hist(b.cur, 3);
+        Stage &st = b.add(ST_FRAC, 1, b.cur_cap + 2);
+        st.timer = QK_KT_AUDIO; st.obj = OB_FRAC;
+        t.frac_cap = b.cur_cap + 8;
+        HIPCHECK(hipMalloc(&t.d_frac_idx, sizeof(int) * t.frac_cap));
+        HIPCHECK(hipMalloc(&t.d_frac_pos, sizeof(double) * t.frac_cap));
+        for (auto &fs : t.frac_slot) {
+            HIPCHECK(hipHostMalloc(&fs.idx, sizeof(int) * t.frac_cap, hipHostMallocMapped));
+            HIPCHECK(hipHostMalloc(&fs.pos, sizeof(double) * t.frac_cap, hipHostMallocMapped));
+            HIPCHECK(hipEventCreateWithFlags(&fs.ev, sync_event_flags()));
+        }
+        t.frac_dindex = 1.0;
+    }
+    for (int q = e->cfg.playback_rate / 48000, k = 0; q > 1; q /= 2, k++) {     // quisk.c:2535-2553
+        b.hbint(1, QK_KT_AUDIO);
+        t.stages.back().obj = OB_PHB0 + k;
+    }
+    t.play = t.aud = b.cur;
+    b.need_hist(b.cur, e->cfg.playback_rate * 15 / 1000);             // AGC_DELAY, quisk.c:30, 2036
+    int rc = alloc_chain_streams(e, t, 2);
+    if (rc != QK_OK) return rc;
+    Stream &pl = t.streams[t.play];
+    const size_t bytes = (size_t)2 * pl.rx_stride() * sizeof(double);
+    HIPCHECK(hipMalloc(&t.play_alt, bytes));
+    HIPCHECK(hipMemsetAsync(t.play_alt, 0, bytes, e->stream));
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    t.built = true;
+    return QK_OK;
+}
+
+// the route's AGC slots follow the receiver's settings: agcReleaseGain and rxMode are globals in the reference (quisk.c:145, 2088)
+static int route_sync_params(qk_engine *e)
+{
+    for (auto &r : e->routes) {
+        if (!r.tail.built) continue;
+        for (int ch = 0; ch < 2; ch++) {
+            HIPCHECK(hipMemcpy(e->d_mode + r.slot + ch, e->d_mode + r.rx, sizeof(int), hipMemcpyDeviceToDevice));
+            HIPCHECK(hipMemcpy(e->d_release_gain + r.slot + ch, e->d_release_gain + r.rx, sizeof(double), hipMemcpyDeviceToDevice));
+        }
+    }
+    return QK_OK;
+}
+
+// A route goes live or stops (all streams idle).  What the reference keeps in ONE place for mono and stereo alike moves with
+// it: cFracDecim's statics and HalfBand7..9 hold the last samples of `d + I d` when the split starts -- both channels continue
+// from the mono history -- and Agc1 (state and delay ring) is the left channel's AGC (quisk.c:2178-2181, 2528-2575).  Agc2
+// (slot + 1) keeps its state from one stretch of stereo to the next.  Going back to mono the left channel's objects return.
+static int route_transfer(qk_engine *e, qk_engine::Route &r, bool to_live)
+{
+    Chain &c = e->cls_chain[e->cls[r.rx]], &t = r.tail;
+    for (auto &ts : t.stages) {
+        if (ts.obj < 0) continue;
+        for (auto &cs : c.stages) {
+            if (cs.obj != ts.obj) continue;
+            const int need = obj_need_of(e, ts.obj);
+            double *cp = hist_tail(e, c, cs.in, r.rx, 0, need);
+            for (int ch = 0; ch < (to_live ? 2 : 1); ch++) {
+                double *tp = hist_tail(e, t, ts.in, ch, 0, need);
+                HIPCHECK(hipMemcpy(to_live ? tp : cp, to_live ? cp : tp, sizeof(double) * need, hipMemcpyDeviceToDevice));
+            }
+            if (ts.kind == ST_FRAC) {
+                if (to_live) t.frac_dindex = c.frac_dindex;
+                else if (c.members.size() == 1) c.frac_dindex = t.frac_dindex;
+            }
+        }
+    }
+    // Agc1: state, "has run", delay ring (the play stream's history, in both twins)
+    const int from = to_live ? r.rx : r.slot, to = to_live ? r.slot : r.rx;
+    HIPCHECK(hipMemcpy(e->d_agc + to, e->d_agc + from, sizeof(AgcState), hipMemcpyDeviceToDevice));
+    e->agc_started[to] = e->agc_started[from];
+    const int flag = e->agc_started[to];
+    HIPCHECK(hipMemcpy(e->d_agc_started + to, &flag, sizeof(int), hipMemcpyHostToDevice));
+    if (!to_live && e->d_agc_started2) HIPCHECK(hipMemcpy(e->d_agc_started2 + to, &flag, sizeof(int), hipMemcpyHostToDevice));
+    if (c.built && e->agc_started[to]) {
+        Stream &cp = c.streams[c.play], &tp = t.streams[t.play];
+        const int h = std::min(cp.hist, tp.hist);
+        double *cbase = c.play_alt + (long long)r.rx * cp.rx_stride() + (cp.hist - h);       // (plane 0: mono; the left channel of DGT-IQ)
+        double *cbase2 = cp.d + (long long)r.rx * cp.rx_stride() + (cp.hist - h);
+        double *tbase = t.play_alt + (tp.hist - h), *tbase2 = tp.d + (tp.hist - h);
+        if (to_live) {
+            HIPCHECK(hipMemcpy(tbase, cbase, sizeof(double) * h, hipMemcpyDeviceToDevice));
+            HIPCHECK(hipMemcpy(tbase2, cbase, sizeof(double) * h, hipMemcpyDeviceToDevice));
+        } else {
+            HIPCHECK(hipMemcpy(cbase, tbase, sizeof(double) * h, hipMemcpyDeviceToDevice));
+            HIPCHECK(hipMemcpy(cbase2, tbase, sizeof(double) * h, hipMemcpyDeviceToDevice));
+        }
+    }
+    return QK_OK;
+}
+
+// The right channel's AGC ring.  Stereo stops: Agc2 keeps its ring for the next stretch (d_agc2_ring), and the play stream's
+// right row -- from now on the imaginary part of Agc1's ring -- starts as zeros: the stereo path stored real samples there
+// (quisk.c:2564-2568).  Stereo starts: Agc2's ring comes back.  The latest history is in the twin that is written next.
+static int route_stereo(qk_engine *e, qk_engine::Route &r, bool on)
+{
+    Chain &t = r.tail;
+    Stream &p = t.streams[t.play];
+    const int bs = e->cfg.playback_rate * 15 / 1000;
+    if (!r.d_agc2_ring) {
+        HIPCHECK(hipMalloc(&r.d_agc2_ring, sizeof(double) * bs));
+        HIPCHECK(hipMemset(r.d_agc2_ring, 0, sizeof(double) * bs));
+    }
+    double *row1[2] = {t.play_alt + p.rx_stride() + (p.hist - bs), p.d + p.rx_stride() + (p.hist - bs)};
+    if (on) {
+        for (double *d : row1) HIPCHECK(hipMemcpy(d, r.d_agc2_ring, sizeof(double) * bs, hipMemcpyDeviceToDevice));
+    } else {
+        HIPCHECK(hipMemcpy(r.d_agc2_ring, row1[0], sizeof(double) * bs, hipMemcpyDeviceToDevice));
+        for (double *d : row1) HIPCHECK(hipMemset(d, 0, sizeof(double) * bs));
+        // how long the two channels can still differ, in output samples: cFracDecim (3 inputs) and the half-band interpolators
+        // (22 inputs each, at doubling rates) -- under 42 samples at the decimated rate -- and then Agc1's ring
+        r.drain = bs + 42LL * (e->cfg.playback_rate / 48000) + 8;
+    }
+    r.stereo = on;
+    return QK_OK;
+}
+
+// bring every route in line with what was asked for: it is stereo while its method is 1..4 and its receiver is not in DGT-IQ
+// (which is stereo by itself: the reference leaves the second channel alone then, quisk.c:2407-2409); behind a stretch of
+// stereo it runs on in mono until the channels agree again (process_device ends that)
+static int routes_refresh(qk_engine *e)
+{
+    bool changed = false;
+    for (auto &r : e->routes) {
+        const bool want = r.method > 0 && e->cls[r.rx] != CL_DGTIQ;
+        if (want == r.stereo) continue;
+        if (want) {
+            if (!r.tail.built) { int rc = build_route_tail(e, r); if (rc != QK_OK) return rc; }
+            if (!r.live) {
+                int rc = route_transfer(e, r, true);
+                if (rc != QK_OK) return rc;
+                r.live = true; changed = true;
+            }
+        }
+        int rc = route_stereo(e, r, want);
+        if (rc != QK_OK) return rc;
+    }
+    if (changed) { int rc = upload_agc_cls(e); if (rc != QK_OK) return rc; }
+    return route_sync_params(e);
+}
+
 int qk_set_stereo_route(qk_engine *e, int rx, int partner_rx, int method)
 {
     ENGINE_ENTER(e); RX_CHECK(e, rx);
-    if (method < 0 || method > 3) return fail(QK_EINVAL, "route method must be 0..3");
+    if (method < 0 || method > 4) return fail(QK_EINVAL, "route method must be 0..4");
     if (method > 0) { RX_CHECK(e, partner_rx); if (partner_rx == rx) return fail(QK_EINVAL, "a receiver cannot be its own partner"); }
     SYNC_ALL(e);
     qk_engine::Route *rt = nullptr;
     for (auto &r : e->routes) if (r.rx == rx) rt = &r;
     if (!rt) {
         if (method == 0) return QK_OK;
-        e->routes.emplace_back();
+        if ((int)e->routes.size() >= QK_MAX_ROUTES) return fail(QK_ERANGE, "too many stereo routes (QK_MAX_ROUTES)");
+        // allocate first, commit to the engine only when everything is there
+        qk_engine::Route nr;
+        nr.rx = rx; nr.slot = e->nrx + 2 * (int)e->routes.size();
+        const size_t fifo_len = (size_t)e->route_cap + e->front.streams[e->front.aud].cap + 64;
+        bool ok = true;
+        for (auto &q : nr.fifo) for (double *&p : q) ok = ok && hipMalloc(&p, sizeof(double) * fifo_len) == hipSuccess;
+        if (!ok) {
+            for (auto &q : nr.fifo) for (double *p : q) if (p) hipFree(p);
+            return fail(QK_ENOMEM, "out of device memory for a route's FIFOs");
+        }
+        e->routes.push_back(nr);
         rt = &e->routes.back();
-        rt->rx = rx;
-        for (auto &q : rt->fifo) for (double *&p : q) HIPCHECK(hipMalloc(&p, sizeof(double) * (e->route_cap + e->out_stride)));
     }
-    if (!e->d_route_tmp) HIPCHECK(hipMalloc(&e->d_route_tmp, sizeof(double2) * (e->route_cap + e->out_stride)));
-    if (rt->method == 0 || method == 0 || rt->partner != partner_rx) rt->nbuf_a = rt->nbuf_b = 0;      // Buffer2Chan(NULL, ...): initialise
-    rt->partner = partner_rx; rt->method = method;
-    return QK_OK;
+    if (rt->method == 0 || method == 0 || rt->partner != partner_rx) rt->nbuf_a = rt->nbuf_b = 0;      // Buffer2Chan(NULL, ...): initialise (quisk.c:2227-2231)
+    if (method > 0) rt->partner = partner_rx;
+    rt->method = method;
+    return routes_refresh(e);
 }
 
 int qk_key_up(qk_engine *e)
@@ -2699,6 +2981,18 @@ int qk_export_audio_device(qk_engine *e, double *dst_dev, size_t dst_stride)
 int qk_debug_tap(qk_engine *e, int which, int rx, double *out, int cap)
 {
     ENGINE_ENTER(e); RX_CHECK(e, rx);
+    if (which == QK_TAP_ROUTE) {        // the pair of a live stereo route in front of its AGCs: out[0] = left, out[1] = right
+        for (auto &r : e->routes) {
+            if (r.rx != rx || !r.live) continue;
+            SYNC_ALL(e);
+            const Stream &p = r.tail.streams[r.tail.play];
+            const int m = std::min(p.n, cap);
+            for (int ch = 0; ch < 2 && m > 0; ch++)
+                HIPCHECK(hipMemcpy(out + (size_t)ch * cap, p.d + (long long)ch * p.rx_stride() + p.hist, sizeof(double) * m, hipMemcpyDeviceToHost));
+            return m;
+        }
+        return fail(QK_EINVAL, "no live route on this receiver");
+    }
     const Stream *s = nullptr;
     Chain &c = e->cls_chain[e->cls[rx]];
     switch (which) {

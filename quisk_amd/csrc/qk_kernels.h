@@ -1927,6 +1927,30 @@ __global__ __launch_bounds__(256) void k_route_combine(const double2 *left, cons
     const bool ml = kill || (mute_l && *mute_l), mr = kill || (mute_r && *mute_r);
     out[i] = make_double2(ml ? 0.0 : left[i].x, mr ? 0.0 : right[i].x);
 }
+// Mono again behind a stretch of stereo (quisk.c:2495-2501, 2573-2575), while the pair's two planes still differ: the
+// reference's mono sample is complex, d + I d, and runs through the SAME cFracDecim / HalfBand7..9 / Agc1 objects as the pair
+// did -- whose imaginary parts hold the right channel's last samples, and whose AGC ring holds real samples only (the stereo
+// path stored creal, quisk.c:2564-2568).  Until those have passed, the two output channels differ: the route keeps running
+// with both rows fed from the receiver, ONE AGC (Agc1: gains from |Re|, k_agc_gain on row 0), and this apply pass, which
+// puts that gain on both rows and limits by |Re| (process_agc with is_cpx == 0 on a complex sample, quisk.c:2056-2066).
+struct DrainArgs { StreamView in; const double *gains; int buf_size, n; const int *started; double2 *out; const int *mute; int kill; };
+__global__ __launch_bounds__(256) void k_route_drain_apply(DrainArgs a)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const double *p0 = sv_ptr(a.in, 0, 0) + i, *p1 = sv_ptr(a.in, 1, 0) + i;
+    double d0, d1;
+    if (!a.started[0]) { d0 = p0[0]; d1 = p1[0]; }
+    else {
+        const double g = a.gains[i];
+        d0 = p0[-a.buf_size] * g; d1 = p1[-a.buf_size] * g;
+        const double m = fabs(d0);
+        if (m > QK_CLIP32) { d0 = d0 / m; d1 = d1 / m; }
+    }
+    if (a.kill || (a.mute && *a.mute)) { d0 = 0.0; d1 = 0.0; }
+    a.out[i] = make_double2(d0, d1);
+}
 // Key-up envelope (quisk.c:2602-2612): the first samples behind a key-up are scaled by a ramp that the host has made with
 // the reference's own additions (env += 1 / (rate * 5 ms), stopping at 1); every receiver's output row gets it.
 __global__ __launch_bounds__(256) void k_keyup_ramp(double2 *out, long long out_stride, const double *factor, int nf, const int *counts_host, int n_rx)

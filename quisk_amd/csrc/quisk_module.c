@@ -67,7 +67,7 @@ static struct {
     double *mrx_frame[QK_MAX_SUBRX]; int mrx_fill[QK_MAX_SUBRX]; int mrx_count, mrx_next;
     int rx_mode;
     /* second-receiver routing (quisk.c:2410-2494): split_rxtx 0..4, multirx_play_method 0..2, multirx_play_channel or -1 */
-    int split_rxtx, play_method, play_channel, rx_tune, tx_tune;
+    int split_rxtx, play_method, play_channel, rx_tune, tx_tune, rit_freq, partner_dirty, multirx_state;
     int vfo_screen, vfo_audio;                      /* change_rates, quisk.c:3874-3886 */
     int scan_blocks, scan_rate, scan_vfo0, scan_deltaf; double scan_valid;      /* change_scan, quisk.c:3865-3872 */
     double *f0; int f0_n, f0_bw, f0_off;            /* the taps of filter slot 0, for the split partner */
@@ -179,19 +179,24 @@ static void release_engine(void)
 }
 
 /* Which receiver is heard beside receiver 0, and in which ear (quisk.c:2410-2494).  Split RX/TX demodulates the same stream a
- * second time at the transmit offset with receiver 0's mode and filter slot 0: the LAST receiver of the engine is kept for
- * that.  The multirx play channel is sub-receiver 1 + index. */
+ * second time at the transmit offset + RIT with receiver 0's mode and filter slot 0 (quisk.c:2411, 2417-2418): the engine is
+ * made with one receiver more than the sub-receivers need (index G.nrx), kept for that alone.  The multirx play channel is
+ * sub-receiver 1 + index.  The partner's mode and filter are sent again only when they changed (a filter upload drains the
+ * engine's pipeline); its tune follows every set_tune. */
 static int update_route(void)
 {
     if (!G.qk) return QK_OK;
     int method = 0, partner = 0;
-    if (G.split_rxtx >= 1 && G.split_rxtx <= 4 && G.nrx >= 2) {
-        partner = G.nrx - 1;
+    if (G.split_rxtx >= 1 && G.split_rxtx <= 4) {
+        partner = G.nrx;
         const int rx_left = G.split_rxtx == 1 ? G.tx_tune < G.rx_tune : G.tx_tune >= G.rx_tune;     /* quisk.c:2424, 2438 */
-        method = G.split_rxtx == 3 ? 0 : G.split_rxtx == 4 ? 3 : (rx_left ? 1 : 2);
-        if (qk_set_mode(G.qk, partner, G.rx_mode) != QK_OK) return QK_EINVAL;
-        if (qk_set_tune(G.qk, partner, G.tx_tune) != QK_OK) return QK_EINVAL;
-        if (G.f0 && qk_set_filters(G.qk, partner, G.f0, G.f0 + G.f0_n, G.f0_n, G.f0_bw, G.f0_off) != QK_OK) return QK_EINVAL;
+        method = G.split_rxtx == 3 ? 4 : G.split_rxtx == 4 ? 3 : (rx_left ? 1 : 2);
+        if (G.partner_dirty) {
+            if (qk_set_mode(G.qk, partner, G.rx_mode) != QK_OK) return QK_EINVAL;
+            if (G.f0 && qk_set_filters(G.qk, partner, G.f0, G.f0 + G.f0_n, G.f0_n, G.f0_bw, G.f0_off) != QK_OK) return QK_EINVAL;
+            G.partner_dirty = 0;
+        }
+        if (qk_set_tune(G.qk, partner, G.tx_tune + G.rit_freq) != QK_OK) return QK_EINVAL;
     } else if (G.play_channel >= 0 && 1 + G.play_channel < G.nrx) {
         partner = 1 + G.play_channel;
         method = G.play_method == 1 ? 1 : G.play_method == 2 ? 2 : 3;                                  /* quisk.c:2474-2493 */
@@ -217,7 +222,9 @@ static PyObject *record_app(PyObject *self, PyObject *args)
     cfg.device = QuiskGetConfigInt("quisk_amd_device", 0);
     cfg.sample_rate = rate;
     cfg.playback_rate = QuiskGetConfigInt("playback_rate", 48000);
-    cfg.n_receivers = G.nrx = QuiskGetConfigInt("quisk_amd_receivers", 1 + QK_MAX_SUBRX);
+    G.nrx = QuiskGetConfigInt("quisk_amd_receivers", 1 + QK_MAX_SUBRX);
+    cfg.n_receivers = G.nrx + 1;                    /* + the split RX/TX partner (update_route) */
+    G.partner_dirty = 1;
     cfg.max_block = QK_SAMP_BUFFER;
     cfg.fft_size = fft; cfg.data_width = dw;
     cfg.reserved[0] = QuiskGetConfigInt("quisk_amd_max_filter_taps", 0);
@@ -276,6 +283,12 @@ static PyObject *set_params(PyObject *self, PyObject *args, PyObject *kw)
         } else if (bscope_size != G.bs_size) {
             printf("Illegal attempt to change bscope_size\n");
         }
+    }
+    if (hermes_pause != -1) {       /* quisk.c:2952-2962: returns the previous quisk_multirx_state; 20 and above = paused */
+        const int prev = G.multirx_state;
+        if (hermes_pause) { if (G.multirx_state < 20) G.multirx_state = 20; }
+        else if (G.multirx_state >= 20) G.multirx_state = 0;
+        return PyLong_FromLong(prev);
     }
     Py_RETURN_NONE;
 }
@@ -353,6 +366,7 @@ static PyObject *set_rx_mode(PyObject *self, PyObject *args)
     if (!need_engine()) return NULL;
     if (qk_set_mode(G.qk, 0, mode) != QK_OK) return engine_error();
     G.rx_mode = mode;
+    G.partner_dirty = 1;
     if (G.split_rxtx && update_route() != QK_OK) return engine_error();
     Py_RETURN_NONE;
 }
@@ -394,6 +408,7 @@ static PyObject *change_scan(PyObject *self, PyObject *args)
 static PyObject *set_split_rxtx(PyObject *self, PyObject *args)
 {   /* quisk.c:4372-4379 */
     if (!PyArg_ParseTuple(args, "i", &G.split_rxtx)) return NULL;
+    G.partner_dirty = 1;
     if (!need_engine()) return NULL;
     if (update_route() != QK_OK) return engine_error();
     Py_RETURN_NONE;
@@ -452,10 +467,11 @@ static PyObject *set_filters(PyObject *self, PyObject *args)
         free(G.f0);
         G.f0 = malloc(sizeof(double) * 2 * (size_t)(size + 1));
         if (G.f0) { memcpy(G.f0, ti, sizeof(double) * (size_t)size); memcpy(G.f0 + size, tq, sizeof(double) * (size_t)size); G.f0_n = (int)size; G.f0_bw = bw; G.f0_off = start_offset; }
+        G.partner_dirty = 1;
         if (rc == QK_OK && G.split_rxtx) rc = update_route();
     }
     else if (nFilter == 1)
-        for (int r = 1; r < G.nrx - (G.split_rxtx ? 1 : 0) && rc == QK_OK; r++) rc = qk_set_filters(G.qk, r, ti, tq, (int)size, bw, start_offset);
+        for (int r = 1; r < G.nrx && rc == QK_OK; r++) rc = qk_set_filters(G.qk, r, ti, tq, (int)size, bw, start_offset);
     free(ti);
     if (rc != QK_OK) return engine_error();
     Py_RETURN_NONE;
@@ -466,7 +482,7 @@ static PyObject *set_agc(PyObject *self, PyObject *args)
     double gain;
     if (!PyArg_ParseTuple(args, "d", &gain)) return NULL;
     if (!need_engine()) return NULL;
-    for (int r = 0; r < G.nrx; r++) if (qk_set_agc(G.qk, r, gain) != QK_OK) return engine_error();
+    for (int r = 0; r <= G.nrx; r++) if (qk_set_agc(G.qk, r, gain) != QK_OK) return engine_error();
     Py_RETURN_NONE;
 }
 static PyObject *set_multirx_mode(PyObject *self, PyObject *args)
@@ -671,6 +687,8 @@ static PyObject *set_sidetone(PyObject *self, PyObject *args)
     double volume;
     if (!PyArg_ParseTuple(args, "idii", &ctrl, &volume, &rit, &keyup)) return NULL;
     if (G.qk && qk_set_rit_freq(G.qk, rit) != QK_OK) return engine_error();
+    G.rit_freq = rit;
+    if (G.qk && G.split_rxtx && update_route() != QK_OK) return engine_error();      /* the second channel is tuned to tx + rit (quisk.c:2411) */
     Py_RETURN_NONE;
 }
 static PyObject *get_squelch(PyObject *self, PyObject *args)

@@ -26,7 +26,7 @@ class QkStats(C.Structure):
 
 
 KT_FRONTEND, KT_DECIM, KT_DEMOD, KT_AUDIO, KT_AGC, KT_FFT = range(6)
-TAP_FRONTEND, TAP_DECIM, TAP_DEMOD, TAP_AUDIO48, TAP_PLAY = range(5)
+TAP_FRONTEND, TAP_DECIM, TAP_DEMOD, TAP_AUDIO48, TAP_PLAY, TAP_ROUTE = range(6)
 
 _lib = None
 
@@ -208,8 +208,13 @@ class Engine:
         return _check(self.L.qk_is_squelch(self.h, int(freq)))
 
     def set_stereo_route(self, rx, partner_rx, method):
-        """Second-receiver routing (quisk.c:2410-2494): 1 = (rx, partner), 2 = (partner, rx), 3 = partner on both, 0 = off."""
+        """Second-receiver routing (quisk.c:2410-2494): 1 = (rx, partner), 2 = (partner, rx), 3 = partner on both, 4 = rx on both through the stereo
+        path, 0 = off."""
         _check(self.L.qk_set_stereo_route(self.h, int(rx), int(partner_rx), int(method)))
+
+    def route_tap(self, rx):
+        """(debug) the pair of receiver rx's live stereo route in front of its two AGCs: [2][count], left and right"""
+        return self.tap(TAP_ROUTE, rx, planes=2, cap=self.out_cap + 32768)
 
     def key_up(self):
         """The key went up: the 5 ms envelope of quisk.c:2602-2612 starts with the next block."""
@@ -261,8 +266,9 @@ class Engine:
         _check(self.L.qk_sync(self.h))
 
     def audio(self, rx):
-        out = np.empty(self.out_cap, dtype=np.complex128)
-        m = _check(self.L.qk_pull_audio(self.h, rx, out.ctypes.data, self.out_cap))
+        cap = max(self.out_cap, _check(self.L.qk_audio_count(self.h, rx)))     # (a stereo route's block can hold what its FIFOs kept back)
+        out = np.empty(cap, dtype=np.complex128)
+        m = _check(self.L.qk_pull_audio(self.h, rx, out.ctypes.data, cap))
         return out[:m].copy()
 
     def audio_all(self):

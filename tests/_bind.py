@@ -158,6 +158,10 @@ def oracle():
     L.qko_graph_change_scan.argtypes = [P(OGraph), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
     L.qko_graph_release.argtypes = [P(OGraph), C.c_double, C.c_double, ddp, P(C.c_double)]
     L.qko_buffer2chan.argtypes = [P(OB2C), ddp, C.c_int, ddp, C.c_int]
+    L.qko_pair_new.restype = C.c_void_p
+    L.qko_pair_delete.argtypes = [C.c_void_p]
+    L.qko_pair_reset_fifos.argtypes = [C.c_void_p]
+    L.qko_rx_pair_process.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, cdp, C.c_int, C.c_int, cdp]
     L.qko_keyup_envelope.argtypes = [C.c_double, cdp, C.c_int, C.c_int]
     L.qko_keyup_envelope.restype = C.c_double
     L.qko_rx_process_many.argtypes = [P(C.c_void_p), C.c_int, cdp, C.c_int, cdp, C.c_long, idp]

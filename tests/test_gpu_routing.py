@@ -1,77 +1,161 @@
-"""Second-receiver routing (split RX/TX and the multirx play channel, quisk.c:2410-2494, with Buffer2Chan's count
-equalisation, quisk.c:1452-1487), per-channel squelch muting (quisk.c:2585-2601) and the key-up envelope
-(quisk.c:2602-2612), against the oracle's receivers combined by the oracle's restatement of Buffer2Chan."""
-import ctypes as C
-
+"""Second-receiver routing (split RX/TX and the multirx play channel, quisk.c:2410-2494) in the reference's order: the two
+DETECTED streams are count-equalised by Buffer2Chan at the decimated rate (quisk.c:1452-1487, 2419, 2473), the pair goes
+through cFracDecim and the play-rate interpolators (quisk.c:2528-2553), Agc1 runs on the left channel and Agc2 on the right
+(quisk.c:2563-2572), then the squelch per channel (quisk.c:2585-2601) and the key-up envelope (quisk.c:2602-2612).  Against the
+oracle's restatement of exactly those lines (qko_rx_pair_process), FROM BLOCK 0: the pair in front of the AGCs within 1e-9
+of the running peak, both AGCs bit-exact on identical input, equal counts."""
 import numpy as np
 import pytest
 
 import _bind as B
-from _rxsetup import configure_engine, make_oracle_rx, TOL
+from _rxsetup import AgcTwin, configure_engine, make_oracle_rx, TOL
 from quisk_amd import Engine
-from quisk_amd.synth import make_iq
+from quisk_amd.engine import TAP_PLAY
 
 pytestmark = pytest.mark.gpu
 
 
 def _steady(n, fs, tunes, modes, seed):
-    """carriers of equal strength well above the noise: the AGCs settle alike in oracle and engine"""
+    """carriers well above the noise on every receiver's frequency"""
     rng = np.random.default_rng(seed)
     t = np.arange(n) / fs
     x = np.zeros(n, dtype=np.complex128)
-    for f, m in zip(tunes, modes):
+    for k, (f, m) in enumerate(zip(tunes, modes)):
         side = -1000.0 if m in (0, 2, 8) else 1000.0
         car = np.exp(1j * (2 * np.pi * (f + side) * t + rng.uniform(0, 6.28)))
         if m == 4:
             car = car * (1 + 0.5 * np.sin(2 * np.pi * 700.0 * t))
         if m == 5:
             car = car * np.exp(1j * 3.0 * np.sin(2 * np.pi * 700.0 * t))
-        x += 2.0 ** 25 * car
+        x += 2.0 ** (25 - 3 * k) * car
     x += 2.0 ** 10 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
     return np.round(x.real) + 1j * np.round(x.imag)
 
 
-@pytest.mark.parametrize("method,modes", [(1, [3, 3]), (2, [3, 1]), (3, [2, 4]), (1, [1, 5])])
-def test_stereo_route_against_buffer2chan(method, modes):
+class Pair:
+    """engine receivers 0 (+ partner 1) beside the oracle's pair; checks one block"""
+
+    def __init__(self, fs, modes, tunes, playback=48000, max_block=9999):
+        self.fs, self.playback, self.modes = fs, playback, modes
+        self.eng = Engine(fs, n_receivers=2, playback_rate=playback, max_block=max_block)
+        configure_engine(self.eng, modes, tunes)
+        self.oa, self.ob = [make_oracle_rx(fs, m, t, playback) for m, t in zip(modes, tunes)]
+        self.L = B.oracle()
+        self.pair = self.L.qko_pair_new()
+        self.twins = [AgcTwin(playback, modes[0]), AgcTwin(playback, modes[0])]       # Agc1, Agc2; rxMode decides the FM target
+        self.peak, self.worst, self.total, self.blocks = 0.0, 0.0, 0, 0
+
+    def stereo_block(self, blk, method):
+        n = len(blk)
+        cap = 8 * (n + 30000)
+        work = np.zeros(cap, np.complex128); pre = np.zeros(cap, np.complex128)
+        work[:n] = blk
+        self.eng.process(blk)
+        m = self.L.qko_rx_pair_process(self.oa.h, self.ob.h, self.pair, work, n, method, pre)
+        got = self.eng.audio(0)
+        assert len(got) == m, (self.blocks, len(got), m)
+        self.blocks += 1
+        if not m:
+            return got, work[:0]
+        want, pre = work[:m], pre[:m]
+        self.peak = max(self.peak, float(np.max(np.abs(pre.real))), float(np.max(np.abs(pre.imag))))
+        gpre = self.eng.route_tap(0)                       # [2][m]: the pair in front of the AGCs
+        assert gpre.shape[1] == m
+        err = max(float(np.max(np.abs(gpre[0] - pre.real))), float(np.max(np.abs(gpre[1] - pre.imag)))) / self.peak
+        self.worst = max(self.worst, err)
+        assert err < TOL, "block %d: pair error %.3e" % (self.blocks, err)
+        import ctypes as C
+        for ch, part in ((0, got.real), (1, got.imag)):
+            tw = self.twins[ch]
+            t = (gpre[ch] + 0j).astype(np.complex128)      # the stereo path hands process_agc real samples (quisk.c:2564-2569)
+            tw.L.qko_agc_process(C.byref(tw.st), t, len(t), 0, tw.rate, tw.gain, 1.0, tw.fm)
+            assert np.array_equal(t.real.view(np.float64), np.ascontiguousarray(part).view(np.float64)), "block %d channel %d: AGC not bit-exact" % (self.blocks, ch)
+        self.total += m
+        return got, want
+
+    def mono_block(self, blk):
+        """mono behind (or in front of) a stretch of stereo: the oracle's receiver alone (its statics are the pair's); the two
+        output channels differ until the right channel's filter histories and the real-only AGC ring have passed"""
+        import ctypes as C
+        self.eng.process(blk)
+        pre, want = self.oa.process_parts(blk)
+        self.ob.process(blk)                               # (the engine's partner keeps running as a receiver of its own)
+        got = self.eng.audio(0)
+        assert len(got) == len(want)
+        self.blocks += 1
+        if len(got):
+            try:
+                rows = self.eng.route_tap(0)               # the route still runs (mono, draining): left and right differ
+                gpre = rows[0] + 1j * rows[1]
+            except Exception:
+                m = self.eng.tap(TAP_PLAY, 0, planes=1)[0]
+                gpre = m + 1j * m
+            self.peak = max(self.peak, float(np.max(np.abs(pre.real))), float(np.max(np.abs(pre.imag))))
+            err = float(np.max(np.abs(gpre - pre))) / self.peak
+            assert err < TOL, "block %d (mono): error %.3e in front of the AGC" % (self.blocks, err)
+            # Agc1 is the mono AGC too, on the complex sample with is_cpx == 0 (quisk.c:2573-2575): bit-exact on identical input
+            tw = self.twins[0]
+            t = np.ascontiguousarray(gpre, dtype=np.complex128)
+            tw.L.qko_agc_process(C.byref(tw.st), t, len(t), 0, tw.rate, tw.gain, 1.0, tw.fm)
+            assert np.array_equal(t.view(np.float64), got.view(np.float64)), "block %d: mono AGC not bit-exact" % self.blocks
+        return got, want
+
+    def close(self):
+        self.L.qko_pair_delete(self.pair)
+        self.oa.close(); self.ob.close(); self.eng.close()
+
+
+@pytest.mark.parametrize("method,modes,fs,playback", [(1, [3, 3], 192000, 48000), (2, [3, 1], 192000, 48000), (3, [2, 4], 192000, 48000),
+                                                      (1, [1, 5], 192000, 48000), (4, [3, 3], 192000, 96000), (2, [4, 0], 250000, 96000)])
+def test_stereo_route_in_the_reference_order(method, modes, fs, playback):
     """Receiver 0 and its partner in different chain classes deliver different counts per block (CW / SSB / AM / FM chains
-    emit on different phases): the FIFOs equalise them."""
-    fs = 192000
-    tunes = [30000, -45000]
+    emit on different phases): the FIFOs equalise them at the decimated rate.  From block 0, ragged blocks; at 250 ksps the
+    pair also goes through cFracDecim, at a 96 k play rate through HalfBand7."""
+    tunes = [int(0.156 * fs), int(-0.234 * fs)]
     sizes = [4800, 4801, 9999, 4800, 1, 4800, 7777, 4800, 4800]
     x = _steady(sum(sizes), fs, tunes, modes, 5)
-    eng = Engine(fs, n_receivers=2, max_block=max(sizes))
-    configure_engine(eng, modes, tunes)
-    eng.set_stereo_route(0, 1, method)
-    oras = [make_oracle_rx(fs, m, t) for m, t in zip(modes, tunes)]
-    b2c = B.OB2C()
-    L = B.oracle()
-    pos, worst, total, uneven = 0, 0.0, 0, False
+    P = Pair(fs, modes, tunes, playback)
+    P.eng.set_stereo_route(0, 1, method)
+    pos = 0
     for n in sizes:
-        blk = x[pos:pos + n]; pos += n
-        eng.process(blk)
-        a = oras[0].process(blk).real.copy(); b = oras[1].process(blk).real.copy()
-        uneven = uneven or len(a) != len(b)
-        cap = max(len(a), len(b)) + 12000
-        aa = np.zeros(cap); bb = np.zeros(cap); aa[:len(a)] = a; bb[:len(b)] = b
-        nout = L.qko_buffer2chan(C.byref(b2c), aa, len(a), bb, len(b))
-        want = {1: aa[:nout] + 1j * bb[:nout], 2: bb[:nout] + 1j * aa[:nout], 3: bb[:nout] + 1j * bb[:nout]}[method]
-        got = eng.audio(0)
-        assert len(got) == nout
-        partner = eng.audio(1)                            # the partner keeps its own (mono) row
-        assert len(partner) == len(b) and (len(b) == 0 or np.max(np.abs(partner.real - b)) <= 1e-6 * max(np.max(np.abs(b)), 1))
-        if nout and pos > 40000:                          # past the AGC's start-up ramp (tests/_rxsetup.py, 3.)
-            worst = max(worst, float(np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1.0)))
-            total += nout
-    assert total > 1000 and worst < TOL
-    if 1 in modes and modes[0] != modes[1]:
-        assert uneven                                     # CW beside another class: the FIFOs did have work
-    eng.set_stereo_route(0, 1, 0)                         # off: mono again
-    eng.process(x[:4800])
-    got = eng.audio(0)
-    assert np.array_equal(got.real, got.imag)
-    for o in oras:
-        o.close()
-    eng.close()
+        got, want = P.stereo_block(x[pos:pos + n], method); pos += n
+    assert P.total > 1000
+    print("route method %d modes %r: worst pair error %.2e over %d samples" % (method, modes, P.worst, P.total))
+    P.close()
+
+
+def test_split_starts_and_stops_midstream():
+    """Mono blocks, then the split is switched on (Agc1 carries on as the left channel's AGC with its ring, Agc2 starts -- its first
+    block passes untouched, quisk.c:2033-2050 --, cFracDecim / HalfBand7 continue from the mono history in both channels), the
+    method is changed without re-initialising Buffer2Chan, then off again (mono continues on Agc1) and on once more (Agc2
+    continues from where it stopped)."""
+    fs, playback = 250000, 96000
+    modes, tunes = [3, 3], [30000, -45000]
+    sizes = [5000, 5001, 4999, 5000]
+    x = _steady(sum(sizes) * 6, fs, tunes, modes, 11)
+    P = Pair(fs, modes, tunes, playback)
+    pos = 0
+    plan = [(0, 3), (1, 4), (2, 3), (0, 3), (3, 4)]
+    b, differed = 0, False
+    for method, k in plan:
+        P.eng.set_stereo_route(0, 1, method)
+        if method and (b == 0 or plan[[p[0] for p in plan].index(method) - 1][0] == 0):
+            P.L.qko_pair_reset_fifos(P.pair)
+        for _ in range(k):
+            n = sizes[b % len(sizes)]; blk = x[pos:pos + n]; pos += n; b += 1
+            if method:
+                P.stereo_block(blk, method)
+            else:
+                got, want = P.mono_block(blk)
+                if len(want):
+                    # (end to end through the AGC: bit-exact on identical input, checked in mono_block; against the oracle's own
+                    # input the AGC's ill-conditioned decisions allow small gain differences, tests/_rxsetup.py 3.)
+                    assert np.max(np.abs(got - want)) <= 1e-4 * max(np.max(np.abs(want)), 1.0), b
+                    assert np.array_equal(got.imag == 0, want.imag == 0), b
+                    if 6 < b <= 11:
+                        differed = differed or bool(np.any(want.real != want.imag))
+    assert P.total > 5000 and differed           # (the reference's mono did differ between its channels behind the stereo stretch)
+    P.close()
 
 
 def test_squelched_partner_is_silent_in_its_channel_only_and_key_up_envelope():
@@ -79,27 +163,30 @@ def test_squelched_partner_is_silent_in_its_channel_only_and_key_up_envelope():
     tunes, modes = [20000, -30000], [3, 5]
     n = 4800
     x = _steady(12 * n, fs, [tunes[0]], [3], 9)           # nothing on the FM partner's frequency: its squelch closes
-    eng = Engine(fs, n_receivers=2, max_block=n)
-    configure_engine(eng, modes, tunes)
-    eng.set_squelch(-30.0)
-    eng.set_stereo_route(0, 1, 1)
-    orx = make_oracle_rx(fs, 3, tunes[0])
-    env, L = 1.0, B.oracle()
+    P = Pair(fs, modes, tunes, max_block=n)
+    P.eng.set_squelch(-30.0)
+    P.oa.set_squelch(-30.0); P.ob.set_squelch(-30.0)
+    P.eng.set_stereo_route(0, 1, 1)
+    env = 1.0
     for b in range(12):
         blk = x[b * n:(b + 1) * n]
         if b == 8:
-            eng.key_up(); env = 0.0                       # quisk.c:2240-2241
-        eng.process(blk)
-        want = orx.process(blk)
-        want = (want.real + 0j).astype(np.complex128)     # left = receiver 0; right = the squelched partner: silence
-        env = L.qko_keyup_envelope(env, want, len(want), 48000)
-        got = eng.audio(0)
+            P.eng.key_up(); env = 0.0                     # quisk.c:2240-2241
+        cap = 8 * (n + 30000)
+        work = np.zeros(cap, np.complex128); work[:n] = blk
+        P.eng.process(blk)
+        m = P.L.qko_rx_pair_process(P.oa.h, P.ob.h, P.pair, work, n, 1, np.zeros(cap, np.complex128))
+        want = work[:m].copy()
+        env = P.L.qko_keyup_envelope(env, want, len(want), 48000)
+        got = P.eng.audio(0)
+        assert len(got) == m
         if b >= 2:
-            assert eng.squelch_active(1) == 1
+            assert P.eng.squelch_active(1) == 1
             assert np.all(got.imag == 0.0) and np.max(np.abs(got.real)) > 0
-        if b >= 6:
-            assert np.max(np.abs(got - want)) <= TOL * np.max(np.abs(want))
+        assert np.array_equal(got.imag == 0, want.imag == 0)
+        if m:
+            assert np.max(np.abs(got - want)) <= 1e-7 * max(np.max(np.abs(want)), 1.0), b
         if b == 8:
             assert abs(got[0].real) < abs(got[200].real) * 0.05        # the ramp starts near zero ...
     assert env == 1.0                                                   # ... and is over after 5 ms
-    orx.close(); eng.close()
+    P.close()

@@ -198,18 +198,29 @@ def test_split_rxtx_and_multirx_play_through_the_extension():
     t = np.arange(12 * 4800) / fs
     x = np.round(2.0 ** 24 * (np.exp(2j * np.pi * (rx_t + 1000) * t) + np.exp(2j * np.pi * (tx_t + 700) * t) + np.exp(2j * np.pi * (30000 + 400) * t)))
     o_rx, o_tx, o_sub = make_oracle_rx(fs, mode, rx_t), make_oracle_rx(fs, mode, tx_t), make_oracle_rx(fs, mode, 30000)
+    L = o_rx.L
+    pair = L.qko_pair_new()                               # Buffer2Chan's FIFOs and Agc2 (quisk.c:1452-1487, 2181)
     QS.set_split_rxtx(1)                                  # stereo, higher frequency is real: tx < rx -> left = receive side
+    worst = 0.0
     for b in range(12):
         blk = x[b * 4800:(b + 1) * 4800]
         if b == 6:
             QS.set_split_rxtx(0); QS.set_multirx_play_method(2); QS.set_multirx_play_channel(0)     # left = sub-receiver 0, right = receiver 0
+            L.qko_pair_reset_fifos(pair)                  # a change of play channel re-initialises Buffer2Chan (quisk.c:2230-2231)
         QS.add_rx_samples(_raw32(blk)); QS.read_sound()
-        a, bb, c = o_rx.process(blk).real, o_tx.process(blk).real, o_sub.process(blk).real
+        work = np.zeros(len(blk) + 30000, np.complex128); work[:len(blk)] = blk
+        pre = np.zeros_like(work)
+        if b < 6:                                         # the reference's order: one pair through cFracDecim / interpolators / Agc1 + Agc2
+            m = L.qko_rx_pair_process(o_rx.h, o_tx.h, pair, work, len(blk), 1, pre)
+            o_sub.process(blk)                            # (the sub-receiver runs beside it, as in the engine)
+        else:
+            m = L.qko_rx_pair_process(o_rx.h, o_sub.h, pair, work, len(blk), 2, pre)
         got = _audio(0)
-        if b in (4, 5):
-            assert rel_err(got, a + 1j * bb) < TOL
-        if b in (10, 11):
-            assert rel_err(got, c + 1j * a) < TOL
+        assert len(got) == m
+        if m:
+            worst = max(worst, rel_err(got, work[:m]))
+    assert worst < 1e-6, worst                            # from block 0, through both AGCs (steady carriers: no AGC decisions at stake)
+    L.qko_pair_delete(pair)
     for o in (o_rx, o_tx, o_sub):
         o.close()
     QS.close_sound()
