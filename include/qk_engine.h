@@ -197,6 +197,32 @@ int qk_add_bscope_samples(qk_engine *e, const double *samples_host, int n);
 int qk_add_bscope_samples_int(qk_engine *e, const void *raw_host, size_t n_bytes, int bytes, int big_endian);
 int qk_get_bandscope(qk_engine *e, int clock, double zoom, double deltaf, double *out, int graph_width, double *adc_level);
 
+/* add_tone (quisk.c:3022-3034) + AddTestTone (quisk.c:1194-1229): a -40 dBFS complex test tone at freq_hz from the centre of the
+ * stream (AM- or FM-modulated with 1 kHz while receiver 0 is in AM / FM / DGT-FM) added to the full-rate stream in front of the
+ * inversion, the noise blanker and the FFT staging; 0 = off.  The tone's vectors carry on from one setting to the next. */
+int qk_add_tone(qk_engine *e, int freq_hz);
+/* get_filter (quisk.c:4761-4848): the frequency response of receiver 0's receive band-pass (filter slot 0), data_width dB values,
+ * negative frequencies first.  Needs an engine made with fft_size >= data_width (the response is shaped by the head of the
+ * display window, as in the reference). */
+int qk_get_filter(qk_engine *e, double *out, int data_width);
+/* measure_audio (quisk.c:3011-3020; the sums at quisk.c:1787-1790, 1873-1876, 1901-1904, 1980-1985, closed at 2015-2018): time > 0
+ * sets the averaging time in seconds (measure_audio_time, default 1); *value = measured_audio, the RMS of receiver 0's detected
+ * audio over that time in millionths of full scale. */
+int qk_measure_audio(qk_engine *e, int time, double *value);
+/* measure_frequency (quisk.c:3000-3009; measure_freq, quisk.c:4850-4920, called from the path at quisk.c:2400-2401): mode >= 0 sets
+ * measure_freq_mode (0 = off; otherwise receiver 0's decimated stream goes through three half-bands into 12000-point frames, and
+ * every mode / 2 frames the strongest line within 500 Hz of the RIT offset is located by its three-bin centroid), mode < 0 only
+ * reads; *value = measured_frequency in Hz from the centre of the stream. */
+int qk_measure_frequency(qk_engine *e, int mode, double *value);
+/* get_audio_graph (quisk.c:966-991; quisk_calc_audio_graph, quisk.c:903-964, fed from the LSB branch at quisk.c:1835): returns 1 and
+ * writes data_width dB values (re full scale, negative frequencies first) when a graph of receiver 0's detected LSB audio is
+ * ready, else 0.  The reference feeds it from every bank in LSB; here receiver 0 alone. */
+int qk_get_audio_graph(qk_engine *e, double *out, int data_width);
+/* The transform behind the module's dft / idft (Xdft, quisk.c:4922-5014): n complex points (interleaved, host memory) through the
+ * engine's FFT, forward or FFTW's unnormalised backward transform; any n up to 2^22.  Rotation, window and 1 / N stay with the
+ * caller. */
+int qk_fft_any(qk_engine *e, const double *in_host, int n, int inverse, double *out_host);
+
 /* get_filter_rate (quisk.c:2661-2735) and PlanDecimation (quisk.c:1509-1547): pure functions. */
 int qk_get_filter_rate(int sample_rate, int mode, int bandwidth);
 int qk_plan_decimation(int sample_rate, int *decim2, int *decim3, int *decim5);

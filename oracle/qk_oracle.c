@@ -518,6 +518,8 @@ struct qko_rx {
     qko_chb45 play_hb[3];                                /* HalfBand7..9, quisk.c:2178-2180 */
     qko_agc agc;                                         /* Agc1, quisk.c:2181 */
     double *audio; int naudio;
+    qko_agraph *agraph;                                  /* quisk_calc_audio_graph's statics, when a test wants the audio graph */
+    double ma_sum, measured_audio; long ma_count; int ma_time;   /* measure_audio (quisk.c:196-201, 1787-1790, 2015-2018) */
 };
 
 #define NOTCH_N 2048                 /* NOTCH_DATA_SIZE and the sizes derived from it, quisk.c:723-729 */
@@ -681,6 +683,7 @@ qko_rx *qko_rx_new(int sample_rate, int playback_rate)
     rx->mode = QKO_USB; rx->tune_vec = 1;
     rx->release_gain = 80; rx->release_time = 1.0;       /* quisk.c:145-146 */
     rx->squelch_level = -999.0;                          /* quisk.c:147 */
+    rx->ma_time = 1;                                     /* quisk.c:201 */
 #define CI(f, nm) do { h = qko_table(#nm, &n); qko_cfir_init(&rx->f, h, n); } while (0)
 #define DI(f, nm) do { h = qko_table(#nm, &n); qko_dfir_init(&rx->f, h, n); } while (0)
     CI(sdriq111, qk_h_sdriq111_114); CI(sdriq53, qk_h_sdriq53_55); CI(sdriq133, qk_h_sdriq133_136);
@@ -878,6 +881,7 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
         for (i = 0; i < n; i++) {
             c = rx_bandpass_iq(rx, x[i]);
             a[i] = rx->mode == QKO_CWL ? creal(c) + cimag(c) : creal(c) - cimag(c);
+            rx->ma_sum += a[i] * a[i]; rx->ma_count += 1;
         }
         audio_hooks(rx, a, n, rx->rit_freq, 0);
         n = qko_dinterpolate(a, n, &rx->aud12p2, 2);
@@ -893,6 +897,7 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
             d = m + rx->dc_remove * 0.99;                /* DC removal, quisk.c:1869-1871 */
             a[i] = d - rx->dc_remove;
             rx->dc_remove = d;
+            rx->ma_sum += a[i] * a[i]; rx->ma_count += 1;
         }
         n = qko_dfilter(a, n, &rx->aud24p6);
         audio_hooks(rx, a, n, 0, 1);
@@ -909,6 +914,7 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
             di = rx->filter_srate * carg(p);
             a[i] = rx->fm_y1 = di * rx->fm_a0 + rx->fm_x1 * rx->fm_a1 - rx->fm_y1 * rx->fm_b1;
             rx->fm_x1 = di;
+            rx->ma_sum += a[i] * a[i]; rx->ma_count += 1;
         }
         n = qko_ddecimate(a, n, &rx->aud24p3, 2);
         n = qko_dfilter(a, n, &rx->fmhp);
@@ -934,6 +940,7 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
         for (i = 0; i < n; i++) {
             c = rx_bandpass_iq(rx, x[i]);
             a[i] = rx->mode == QKO_DGT_L ? creal(c) + cimag(c) : creal(c) - cimag(c);
+            rx->ma_sum += a[i] * a[i]; rx->ma_count += 1;
         }
         audio_hooks(rx, a, n, 0, 0);                     /* quisk.c:1940-1941, 1966-1967 */
         if (narrow) {
@@ -946,6 +953,7 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
         rx->filter_srate = rx->decim_srate;
         if (rx->bandwidth < 19000)
             for (i = 0; i < n; i++) x[i] = rx_bandpass_real(rx, x[i]);
+        for (i = 0; i < n; i++) { rx->ma_sum += creal(x[i] * conj(x[i])); rx->ma_count += 1; }     /* quisk.c:1980-1985 */
         break;
     default:        /* LSB, USB and every mode the reference's switch sends to its default label */
         rx->filter_srate = rx->decim_srate / 4;
@@ -954,14 +962,22 @@ int qko_rx_demodulate(qko_rx *rx, qko_cd *x, double *a, int n)
         for (i = 0; i < n; i++) {
             c = rx_bandpass_iq(rx, x[i]);
             a[i] = rx->mode == QKO_LSB ? creal(c) + cimag(c) : creal(c) - cimag(c);
+            rx->ma_sum += a[i] * a[i]; rx->ma_count += 1;
         }
         audio_hooks(rx, a, n, 0, 1);
+        if (rx->mode == QKO_LSB && rx->agraph) qko_audio_graph_add(rx->agraph, a, n);      /* quisk.c:1835 */
         n = qko_dinterpolate(a, n, &rx->aud24p4, 2);
         n = qko_dinterp2hb45(a, n, &rx->dem_hb7);
         break;
     }
+    if (rx->ma_count >= (long)rx->filter_srate * rx->ma_time) {      /* quisk.c:2015-2018 */
+        rx->measured_audio = sqrt(rx->ma_sum / rx->ma_count) / QKO_CLIP32 * 1e6;
+        rx->ma_sum = 0; rx->ma_count = 0;
+    }
     return n;
 }
+double qko_rx_measure_audio(qko_rx *rx, int time) { if (time > 0) rx->ma_time = time; return rx->measured_audio; }   /* quisk.c:3011-3020 */
+void qko_rx_set_audio_graph(qko_rx *rx, qko_agraph *g) { rx->agraph = g; }
 
 int qko_rx_pre_agc(qko_rx *rx, qko_cd *x, int n)
 {   /* quisk_process_samples up to the AGC (quisk.c:2350-2553): stereo samples at the play rate */
@@ -1199,6 +1215,170 @@ int qko_graph_release(qko_graph *g, double zoom, double deltaf, double *out, dou
     for (i = 0; i < N; i++) g->avg[i] = 0;
     g->count = 0;
     return count;
+}
+
+/* ---- test tone, filter response, frequency measurement, audio graph ---------------------- */
+void qko_tone_init(qko_tone *t) { t->tone = 21474836.47; t->audio = 1.0; }       /* quisk.c:1197-1198 */
+void qko_add_test_tone(qko_tone *t, qko_cd *x, int n, int freq, int sample_rate, int mode)
+{   /* add_tone (quisk.c:3022-3034) + AddTestTone (quisk.c:1194-1229) */
+    int i;
+    qko_cd phase, aphase;
+    if (!freq) return;
+    phase = cexp((I * 2.0 * M_PI * freq) / sample_rate);
+    aphase = cexp(I * 2.0 * M_PI * 1000 / sample_rate);
+    switch (mode) {
+    default:
+        for (i = 0; i < n; i++) { x[i] += t->tone; t->tone *= phase; }
+        break;
+    case QKO_AM:
+        for (i = 0; i < n; i++) { x[i] += t->tone * (1.0 + creal(t->audio)); t->tone *= phase; t->audio *= aphase; }
+        break;
+    case QKO_FM: case QKO_DGT_FM:
+        for (i = 0; i < n; i++) { x[i] += t->tone * cexp(I * creal(t->audio)); t->tone *= phase; t->audio *= aphase; }
+        break;
+    }
+}
+
+void qko_get_filter(const double *fi, const double *fq, int nfilt, int data_width, int fft_size, double *out)
+{   /* get_filter, quisk.c:4761-4848 */
+    int i, j, k, n, freq, time, W = data_width, T = data_width + nfilt;
+    double *average = (double *)malloc(sizeof(double) * T), *bufI = (double *)calloc(nfilt + 1, sizeof(double)),
+           *bufQ = (double *)calloc(nfilt + 1, sizeof(double)), *window = (double *)malloc(sizeof(double) * fft_size);
+    qko_cd *samples = (qko_cd *)calloc(W, sizeof(qko_cd));
+    double phase, delta, d2, accI, accQ, scale;
+    qko_hann_window(window, fft_size);
+    for (i = 0; i < T; i++) average[i] = 0.5;
+    for (freq = 1; freq < W / 2.0 - 10.0; freq++) {
+        delta = 2 * M_PI / W * freq;
+        phase = 0;
+        for (time = 0; time < T; time++) {
+            average[time] += cos(phase);
+            phase += delta;
+            if (phase > 2 * M_PI) phase -= 2 * M_PI;
+        }
+    }
+    n = 0;
+    for (time = 0; time < T; time++) {
+        d2 = average[time];
+        accI = accQ = 0;
+        if (nfilt > 0) {
+            bufI[n] = d2; bufQ[n] = d2;
+            j = n;
+            for (k = 0; k < nfilt; k++) {
+                accI += bufI[j] * fi[k];
+                accQ += bufQ[j] * fq[k];
+                if (++j >= nfilt) j = 0;
+            }
+            if (++n >= nfilt) n = 0;
+        }
+        if (time >= nfilt) samples[time - nfilt] = accI + I * accQ;
+    }
+    for (i = 0; i < W; i++) samples[i] *= window[i];
+    qko_fft(samples, W);
+    scale = 1. / W;
+    for (k = 0; k < W; k++) {
+        d2 = cabs(samples[k]) * scale;
+        average[k] = d2 <= 1e-7 ? -7 : log10(d2);
+    }
+    i = 0;
+    for (k = W / 2; k < W; k++, i++) out[i] = 20.0 * average[k];
+    for (k = 0; k < W / 2; k++, i++) out[i] = 20.0 * average[k];
+    free(average); free(bufI); free(bufQ); free(window); free(samples);
+}
+
+#define MF_N 12000
+void qko_mfreq_init(qko_mfreq *m)
+{   /* measure_freq(NULL, ...), quisk.c:4866-4876 */
+    int i;
+    memset(m, 0, sizeof *m);
+    m->samples = (qko_cd *)malloc(sizeof(qko_cd) * MF_N);
+    m->window = (double *)malloc(sizeof(double) * MF_N);
+    m->average = (double *)calloc(MF_N, sizeof(double));
+    for (i = 0; i < MF_N; i++) m->window[i] = 0.50 - 0.50 * cos(2. * M_PI * i / (MF_N - 1));
+}
+void qko_mfreq_free(qko_mfreq *m) { free(m->samples); free(m->window); free(m->average); free(m->hb[0].scratch); free(m->hb[1].scratch); free(m->hb[2].scratch); free(m->buf); memset(m, 0, sizeof *m); }
+double qko_measure_freq(qko_mfreq *m, const qko_cd *x, int n, int srate, int mode, int rit_freq, int rx_tune)
+{   /* measure_freq, quisk.c:4877-4919; returns measured_frequency */
+    int i, k, center, ipeak;
+    double dmax, c3, freq;
+    if (n > m->nbuf) { free(m->buf); m->nbuf = n * 2; m->buf = (qko_cd *)malloc(sizeof(qko_cd) * m->nbuf); }
+    memcpy(m->buf, x, (size_t)n * sizeof(qko_cd));
+    n = qko_cdecim2hb45(m->buf, n, &m->hb[0]);
+    n = qko_cdecim2hb45(m->buf, n, &m->hb[1]);
+    n = qko_cdecim2hb45(m->buf, n, &m->hb[2]);
+    srate /= 8;
+    for (i = 0; i < n && m->index < MF_N; i++, m->index++) m->samples[m->index] = m->buf[i];
+    if (m->index < MF_N) return m->value;
+    for (i = 0; i < MF_N; i++) m->samples[i] *= m->window[i];
+    qko_fft(m->samples, MF_N);
+    m->index = 0;
+    m->count++;
+    k = 0;
+    for (i = MF_N / 2; i < MF_N; i++) m->average[k++] += cabs(m->samples[i]);
+    for (i = 0; i < MF_N / 2; i++) m->average[k++] += cabs(m->samples[i]);
+    if (m->count < mode / 2) return m->value;
+    m->count = 0;
+    dmax = 1.e-20; ipeak = 0;
+    center = MF_N / 2 - rit_freq * MF_N / srate;
+    k = 500; k = k * MF_N / srate;
+    for (i = center - k; i <= center + k; i++)
+        if (m->average[i] > dmax) { dmax = m->average[i]; ipeak = i; }
+    c3 = 1.36 * (m->average[ipeak + 1] - m->average[ipeak - 1]) / (m->average[ipeak - 1] + m->average[ipeak] + m->average[ipeak + 1]);
+    freq = srate * (2 * (ipeak + c3) - MF_N) / 2 / MF_N;
+    freq += rx_tune;
+    m->value = freq;
+    memset(m->average, 0, sizeof(double) * MF_N);
+    return m->value;
+}
+
+qko_mfreq *qko_mfreq_new(void) { qko_mfreq *m = (qko_mfreq *)malloc(sizeof *m); qko_mfreq_init(m); return m; }
+void qko_mfreq_delete(qko_mfreq *m) { if (m) { qko_mfreq_free(m); free(m); } }
+qko_agraph *qko_audio_graph_new(int data_width) { qko_agraph *g = (qko_agraph *)calloc(1, sizeof *g); g->data_width = data_width; return g; }
+void qko_audio_graph_delete(qko_agraph *g) { if (g) { free(g->window); free(g->average); free(g->fft); free(g); } }
+void qko_audio_graph_add(qko_agraph *g, const double *d, int n)
+{   /* quisk_calc_audio_graph(pow(2, 31) - 1, NULL, dsamples, nSamples, 1), quisk.c:903-964 */
+    int i, k, inp, N = g->data_width;
+    double scale = pow(2, 31) - 1;
+    if (!g->planned) {
+        g->planned = 1;
+        g->count_limit = 8000 / N / 5;
+        if (g->count_limit <= 0) g->count_limit = 1;
+        g->window = (double *)malloc(N * sizeof(double));
+        g->average = (double *)calloc(N, sizeof(double));
+        g->fft = (qko_cd *)malloc(N * sizeof(qko_cd));
+        for (i = 0; i < N; i++) g->window[i] = 0.50 - 0.50 * cos(2. * M_PI * i / N);
+        return;
+    }
+    if (g->ready) return;
+    scale *= N / 2.0;
+    scale *= g->count_limit;
+    scale *= 0.5;
+    for (inp = 0; inp < n; inp++) {
+        g->fft[g->index] = d[inp] / scale;
+        if (++g->index >= N) {
+            g->index = 0;
+            for (i = 0; i < N; i++) g->fft[i] *= g->window[i];
+            qko_fft(g->fft, N);
+            g->count++;
+            k = 0;
+            for (i = N / 2; i < N; i++) g->average[k++] += cabs(g->fft[i]);
+            for (i = 0; i < N / 2; i++) g->average[k++] += cabs(g->fft[i]);
+            if (g->count >= g->count_limit) { g->ready = 1; g->count = 0; }
+        }
+    }
+}
+int qko_audio_graph_get(qko_agraph *g, double *out)
+{   /* get_audio_graph, quisk.c:966-991 */
+    int i;
+    if (!g->ready) return 0;
+    for (i = 0; i < g->data_width; i++) {
+        double d2 = g->average[i];
+        if (d2 < 1E-10) d2 = 1E-10;
+        out[i] = 20.0 * log10(d2);
+        g->average[i] = 0;
+    }
+    g->ready = 0;
+    return 1;
 }
 
 /* ---- second-receiver routing ----------------------------------------------------------- */

@@ -145,6 +145,28 @@ void qko_graph_add_frame(qko_graph *g, qko_cd *frame);
  * out has data_width doubles; *smeter receives the S-meter value (quisk.c:4728-4737). */
 int qko_graph_release(qko_graph *g, double zoom, double deltaf, double *out, double *smeter);
 
+/* add_tone + AddTestTone (quisk.c:3022-3034, 1194-1229): testtoneVector and audioVector as a struct */
+typedef struct { qko_cd tone, audio; } qko_tone;
+void qko_tone_init(qko_tone *t);
+void qko_add_test_tone(qko_tone *t, qko_cd *x, int n, int freq, int sample_rate, int mode);
+/* get_filter (quisk.c:4761-4848): data_width dB values, negative frequencies first */
+void qko_get_filter(const double *fi, const double *fq, int nfilt, int data_width, int fft_size, double *out);
+/* measure_freq (quisk.c:4850-4920), its statics as a struct; x: the decimated samples of a block (untouched) */
+typedef struct { int index, count, nbuf; double value; qko_cd *samples, *buf; double *window, *average; qko_chb45 hb[3]; } qko_mfreq;
+void qko_mfreq_init(qko_mfreq *m);
+void qko_mfreq_free(qko_mfreq *m);
+double qko_measure_freq(qko_mfreq *m, const qko_cd *x, int n, int srate, int mode, int rit_freq, int rx_tune);
+/* quisk_calc_audio_graph / get_audio_graph (quisk.c:903-991), their statics as a struct */
+typedef struct { int data_width, planned, index, count, count_limit, ready; double *window, *average; qko_cd *fft; } qko_agraph;
+qko_agraph *qko_audio_graph_new(int data_width);
+void qko_audio_graph_delete(qko_agraph *g);
+void qko_audio_graph_add(qko_agraph *g, const double *d, int n);
+int qko_audio_graph_get(qko_agraph *g, double *out);
+void qko_rx_set_audio_graph(qko_rx *rx, qko_agraph *g);       /* receiver rx feeds g from its LSB branch (quisk.c:1835) */
+double qko_rx_measure_audio(qko_rx *rx, int time);           /* measure_audio, quisk.c:3011-3020 */
+qko_mfreq *qko_mfreq_new(void);
+void qko_mfreq_delete(qko_mfreq *m);
+
 /* Buffer2Chan (quisk.c:1452-1487), its statics as a struct (zero-initialised); and the key-up envelope (quisk.c:2602-2612) */
 #define QKO_B2C_SIZE 12000
 typedef struct { int nbuf1, nbuf2; double buf1[QKO_B2C_SIZE], buf2[QKO_B2C_SIZE]; } qko_b2c;

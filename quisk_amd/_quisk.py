@@ -496,18 +496,149 @@ def change_scan(scan_blocks, scan_sample_rate, scan_valid, scan_vfo0, scan_delta
         s.eng.change_scan(*s.scan, s.tx_tune, s.vfo_screen)
 
 
+def add_tone(freq):
+    """quisk.c:3022-3034."""
+    _st().eng.add_tone(int(freq))
+
+
+def get_filter():
+    """quisk.c:4761-4848: a tuple of data_width dB values."""
+    s = _st()
+    return tuple(float(v) for v in s.eng.get_filter(s.data_width))
+
+
+def get_tx_filter():
+    """microphone.c:719-807: the transmit chain is off the path; the reference's shape at its floor."""
+    return tuple(-140.0 for _ in range(_st().data_width))
+
+
+def get_audio_graph():
+    """quisk.c:966-991: None until a graph is ready."""
+    g = _st().eng.get_audio_graph()
+    return None if g is None else tuple(float(v) for v in g)
+
+
+def measure_frequency(mode):
+    """quisk.c:3000-3009."""
+    return _st().eng.measure_frequency(int(mode))
+
+
+def measure_audio(time):
+    """quisk.c:3011-3020."""
+    return _st().eng.measure_audio(int(time))
+
+
+def _xdft(seq, inverse, window):
+    """Xdft, quisk.c:4922-5014: order of frequency with zero at index (size - 1) / 2, Blackman window, 1 / N on the inverse."""
+    try:
+        size = len(seq)
+    except TypeError:
+        raise error("DFT input data is not a sequence")
+    if size <= 0:
+        return ()
+    j0 = (size - 1) // 2
+    try:
+        x = np.array([complex(seq[(j0 + i) % size]) for i in range(size)], dtype=np.complex128)
+    except (TypeError, ValueError):
+        raise error("DFT input data is not a complex/float/int number")
+    w = None
+    if window:
+        w = np.zeros(size + 1)
+        for i in range(size // 2 + 1):
+            w[i] = w[size - i] = 0.42 + 0.50 * np.cos(2. * np.pi * i / size) + 0.08 * np.cos(4. * np.pi * i / size)
+        w = w[:size]
+    if not inverse and w is not None:
+        x = x * w
+    y = _st().eng.fft_any(x, inverse)
+    if inverse:
+        y = y * (w / size) if w is not None else y / size
+    out = [0j] * size
+    for i in range(size):
+        out[(j0 + i) % size] = complex(y[i])
+    return out
+
+
+def dft(seq, window=0):
+    return _xdft(seq, False, window)
+
+
+def idft(seq, window=0):
+    return _xdft(seq, True, window)
+
+
+def sound_devices():
+    return ([], [])
+
+
+pa_sound_devices = sound_devices
+
+
+def sound_errors():
+    return []
+
+
+def ip_interfaces():
+    return []
+
+
+def get_hermes_adc():
+    return 0.0
+
+
+def get_hermes_TFRC():
+    return (0.0, 0.0, 0.0, 0.0)
+
+
+def get_hermeslite_writepointer():
+    return 0
+
+
+def get_hermeslite_response():
+    return bytearray(5)
+
+
+def hermes_to_pc():
+    return bytearray(20)
+
+
+def freedv_get_snr():
+    return 0.0
+
+
+def freedv_get_version():
+    return -1
+
+
+def freedv_get_rx_char():
+    return ""
+
+
 def _inert(*args, **kw):
     return None
 
 
+def _zero(*args, **kw):
+    return 0
+
+
+is_key_down = get_hardware_ptt = is_vox = _zero       # receive only: the key is up
+
+
+def get_squelch(freq):
+    """get_squelch (quisk.c:2645-2652) = IsSquelch on the last released graph row."""
+    return _st().eng.is_squelch(int(freq))
+
+
 # Entries of QuiskMethods outside the receive path: accepted and ignored.
 INERT = ("set_volume", "set_enable_bandscope",
-         "add_tone", "set_spot_level", "set_imd_level", "set_key_down", "set_ctcss", "set_tx_audio", "set_record_state",
+         "test_1", "test_2", "test_3", "set_spot_level", "set_imd_level", "set_key_down", "set_ctcss", "set_tx_audio", "set_record_state",
          "set_file_name", "set_transmit_mode", "set_fdx", "set_sample_bytes",
          "change_rate", "start_sound", "open_sound", "open_key", "close_key",
          "open_rx_udp", "close_rx_udp", "set_hermes_id", "set_hermes_filters", "set_alex_hpf", "set_alex_lpf",
          "set_hermeslite_writepointer", "clear_hermeslite_response", "set_hermeslite_writequeue", "pc_to_hermes",
-         "pc_to_hermeslite_writequeue", "freedv_open", "freedv_close", "freedv_set_options", "set_freedv_mode")
+         "pc_to_hermeslite_writequeue", "freedv_open", "freedv_close", "freedv_set_options", "set_freedv_mode",
+         "record_graph", "ImmediateChange", "set_ampl_phase", "set_udp_tx_correct", "set_mic_out_volume", "tx_hold_state",
+         "open_wav_file_play", "capt_channels", "play_channels", "micplay_channels", "mixer_set", "set_PTT")
 for _name in INERT:
     globals()[_name] = _inert
 del _name

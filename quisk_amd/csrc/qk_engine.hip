@@ -77,6 +77,8 @@ struct Stage {
     // second user's samples of a block stored behind the first user's, and both move the same decimation counter
     bool in_after = false, out_after = false;   // this stage's input / output starts behind the first user's samples of the block
     int phase_share = -1;      // index of the stage whose `phase` is this stage's counter too
+    int measure_div = 0;       // > 0: receiver 0's output of this stage is what measure_audio sums (quisk.c:1787-1790 ...); the stage's
+                               // rate is decim_srate / measure_div (quisk_filter_srate)
     long long total_in = 0;    // ST_RXF: samples this stage has taken in since the engine was made (ring positions, see RingImage)
     int obj = OB_NONE;         // the reference's filter object this stage stands for, if a receiver can carry it between classes
 };
@@ -186,6 +188,24 @@ struct qk_engine {
     int dc_bw = 0, invert = 0;
     double dc_alpha = 0.95; int dc_alpha_bw = -1;
     long long dc_key_delay = 0, dc_count = 0;
+    // measure_audio (quisk.c:3011-3020): d_ma[0] = running sum of squares, d_ma[1] = measured_audio
+    double *d_ma = nullptr; long long ma_count = 0; int ma_time = 1;
+    // measure_frequency (quisk.c:3000-3009; measure_freq, quisk.c:4850-4920): three half-bands on receiver 0's decimated stream,
+    // frames of 12000 samples, Hanning window, magnitude average in order of frequency, peak search around the RIT offset
+    int mf_mode = 0, mf_index = 0, mf_count = 0; double mf_value = 0.0;
+    Chain mf_chain; AnyFft *mf_fft = nullptr; double2 *d_mf_frame = nullptr, *d_mf_X = nullptr; double *d_mf_avg = nullptr;
+    // audio graph (quisk_calc_audio_graph, quisk.c:903-964; get_audio_graph, quisk.c:966-991): frames of data_width detected
+    // LSB samples of receiver 0
+    int ag_index = 0, ag_count = 0, ag_ready = 0, ag_N = 0, ag_frames = 1; bool ag_inited = false;
+    AnyFft *ag_fft = nullptr; double2 *d_ag_frame = nullptr, *d_ag_X = nullptr; double *d_ag_avg = nullptr;
+    // test tone (AddTestTone, quisk.c:1194-1229): power tables of the tone's and the audio vector's phase steps, the two
+    // vectors at the next block's first sample (ping-pong), the block with the tone in it
+    int tone_freq = 0, tone_pp = 0;
+    double2 *d_tone_tab = nullptr, *d_tone_state[2] = {nullptr, nullptr}, *d_tone_buf = nullptr;
+    // host copy of receiver 0's band-pass taps in the reference's order (cFilterI[0] / cFilterQ[0]: get_filter reads them)
+    std::vector<double> f0_i, f0_q;
+    // a plain transform of any size for the module's dft / idft / get_filter (quisk.c:4761-4848, 4922-5046)
+    AnyFft *gen = nullptr; int gen_n = 0; double2 *d_gen_in = nullptr, *d_gen_out = nullptr;
     // noise blanker (k_nb_*): two sets of history arrays (a block reads one and leaves the next block's history in the other)
     int nb_level = 0, nb_hw = 0, nb_H = 0, nb_set = 0;
     double2 *d_nb_x[2] = {nullptr, nullptr}, *d_nb_y = nullptr;
@@ -558,6 +578,9 @@ static int build_class(qk_engine *e, int cl)
             /* CL_DGTW  */ {OB_CRX, OB_NONE, OB_NONE, OB_NONE, OB_NONE, OB_NONE, OB_NONE, OB_NONE},
             /* CL_DGTIQ */ {OB_DRX, OB_NONE, OB_NONE, OB_NONE, OB_NONE, OB_NONE, OB_NONE, OB_NONE}};
         for (size_t i = 0; i < c.stages.size() && i < 8; i++) c.stages[i].obj = ids[cl][i];
+        // the stage whose output measure_audio sums for bank 0, and the divisor of its rate (quisk_filter_srate)
+        static const int mstage[CL_COUNT][2] = {{2, 4}, {3, 8}, {2, 2}, {2, 1}, {0, 1}, {0, 1}};
+        c.stages[mstage[cl][0]].measure_div = mstage[cl][1];
     }
     c.aud = b.cur;
     // tail: fractional decimator when the decimated rate is not 48000 (quisk.c:2528-2532) ...
@@ -936,6 +959,8 @@ static int init_receivers(qk_engine *e)
         HIPCHECK(hipMalloc(&e->d_agc_started2, nrx * sizeof(int)));
         HIPCHECK(hipMemset(e->d_agc_started2, 0, nrx * sizeof(int)));
     }
+    HIPCHECK(hipMalloc(&e->d_ma, 2 * sizeof(double)));
+    HIPCHECK(hipMemset(e->d_ma, 0, 2 * sizeof(double)));
     HIPCHECK(hipMalloc(&e->d_sq_state, nrx * 3 * sizeof(double)));
     HIPCHECK(hipMemset(e->d_sq_state, 0, nrx * 3 * sizeof(double)));
     e->sq_pstride = cfg.max_block / 256 + 8;        // the discriminator's workgroups: its stream is never longer than the input block
@@ -1473,6 +1498,103 @@ static int release_graph(qk_engine *e, double zoom, double deltaf, double *out, 
     return graph_collect(e, out, smeter);
 }
 
+// quisk_calc_audio_graph (quisk.c:903-964) on receiver 0's detected LSB audio: frames of data_width samples, scaled to 0 dB =
+// 2^31 - 1 for a real signal behind a Hanning window, magnitudes of audio_fft_count frames added in order of frequency; once
+// a graph is ready further blocks are ignored until get_audio_graph has taken it.  `delay`: the samples are read this far back
+// (d_delay in front of the call while the SSB squelch is on, quisk.c:1831-1835).
+static int audio_graph_block(qk_engine *e, const Stream &s, int delay, hipStream_t cs)
+{
+    const int N = e->cfg.data_width;
+    if (N < 2) return QK_OK;
+    if (!e->ag_inited) {            // the first call only makes the plan and the window (quisk.c:915-933)
+        e->ag_N = N;
+        e->ag_frames = std::max(1, 8000 / N / 5);
+        std::vector<double> win(N);
+        for (int i = 0; i < N; i++) win[i] = 0.50 - 0.50 * cos(2. * M_PI * i / N);
+        int rc = any_init(e, e->ag_fft, N, win.data());
+        if (rc != QK_OK) return rc;
+        HIPCHECK(hipMalloc(&e->d_ag_frame, sizeof(double2) * N));
+        HIPCHECK(hipMalloc(&e->d_ag_X, sizeof(double2) * N));
+        HIPCHECK(hipMalloc(&e->d_ag_avg, sizeof(double) * N));
+        HIPCHECK(hipMemset(e->d_ag_avg, 0, sizeof(double) * N));
+        e->ag_inited = true;
+        return QK_OK;
+    }
+    if (e->ag_ready) return QK_OK;
+    const double scale = (pow(2, 31) - 1) * (N / 2.0) * e->ag_frames * 0.5;
+    int pos = 0;
+    while (pos < s.n) {
+        const int take = std::min(s.n - pos, N - e->ag_index);
+        hipLaunchKernelGGL(k_frame_collect, dim3((take + 255) / 256), dim3(256), 0, cs, s.view(), 1, pos - delay, take, e->d_ag_frame, e->ag_index, scale);
+        pos += take; e->ag_index += take;
+        if (e->ag_index >= N) {
+            e->ag_index = 0;
+            any_run(e, e->ag_fft, cs, e->d_ag_frame, nullptr, e->d_ag_X);
+            hipLaunchKernelGGL(k_frame_accum, dim3((N + 255) / 256), dim3(256), 0, cs, e->d_ag_X, N, e->d_ag_avg);
+            if (++e->ag_count >= e->ag_frames) { e->ag_ready = 1; e->ag_count = 0; }
+        }
+    }
+    return QK_OK;
+}
+
+static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_list, int nlist, hipStream_t cs);
+// measure_freq (quisk.c:4850-4920) on receiver 0's decimated stream
+static int measure_freq_block(qk_engine *e, const Stream &dec)
+{
+    const int N = 12000;
+    hipStream_t cs = e->stream;
+    Chain &c = e->mf_chain;
+    if (!c.built) {
+        ChainBuilder b(c, dec.cap);
+        for (int i = 0; i < 3; i++) b.fir(e->f_hbdec, 2, -1);
+        if (dec.hist < b.in_hist) return fail(QK_EINVAL, "internal: decimated stream history too small for measure_freq");
+        int rc = alloc_chain_streams(e, c, 1);
+        if (rc != QK_OK) return rc;
+        std::vector<double> win(N);
+        for (int i = 0; i < N; i++) win[i] = 0.50 - 0.50 * cos(2. * M_PI * i / (N - 1));     // quisk.c:4873-4874
+        rc = any_init(e, e->mf_fft, N, win.data());
+        if (rc != QK_OK) return rc;
+        HIPCHECK(hipMalloc(&e->d_mf_frame, sizeof(double2) * N));
+        HIPCHECK(hipMalloc(&e->d_mf_X, sizeof(double2) * N));
+        HIPCHECK(hipMalloc(&e->d_mf_avg, sizeof(double) * N));
+        HIPCHECK(hipMemset(e->d_mf_avg, 0, sizeof(double) * N));
+        HIPCHECK(hipStreamSynchronize(e->stream));
+        c.built = true;
+    }
+    int rc = run_chain(e, c, dec, nullptr, 1, cs);
+    if (rc != QK_OK) return rc;
+    const Stream &o = c.streams.back();
+    const int srate = e->decim_srate / 8;
+    const int take = std::min(o.n, N - e->mf_index);      // what does not fit the frame is dropped (quisk.c:4881-4884)
+    if (take > 0) {
+        hipLaunchKernelGGL(k_frame_collect, dim3((take + 255) / 256), dim3(256), 0, cs, o.view(), 2, 0, take, e->d_mf_frame, e->mf_index, 1.0);
+        e->mf_index += take;
+    }
+    if (e->mf_index < N) return QK_OK;
+    e->mf_index = 0;
+    any_run(e, e->mf_fft, cs, e->d_mf_frame, nullptr, e->d_mf_X);
+    hipLaunchKernelGGL(k_frame_accum, dim3((N + 255) / 256), dim3(256), 0, cs, e->d_mf_X, N, e->d_mf_avg);
+    if (++e->mf_count < e->mf_mode / 2) return QK_OK;
+    // time for a calculation (quisk.c:4898-4918): a few times a minute, on the host
+    e->mf_count = 0;
+    std::vector<double> avg(N);
+    HIPCHECK(hipMemcpyAsync(avg.data(), e->d_mf_avg, sizeof(double) * N, hipMemcpyDeviceToHost, cs));
+    HIPCHECK(hipMemsetAsync(e->d_mf_avg, 0, sizeof(double) * N, cs));
+    HIPCHECK(hipStreamSynchronize(cs));
+    double dmax = 1.e-20;
+    int ipeak = 0;
+    const int center = N / 2 - e->rit_freq * N / srate;
+    const int k = 500 * N / srate;
+    for (int i = center - k; i <= center + k; i++)
+        if (i >= 0 && i < N && avg[i] > dmax) { dmax = avg[i]; ipeak = i; }
+    if (ipeak < 1 || ipeak > N - 2) return QK_OK;
+    const double c3 = 1.36 * (avg[ipeak + 1] - avg[ipeak - 1]) / (avg[ipeak - 1] + avg[ipeak] + avg[ipeak + 1]);
+    double freq = srate * (2 * (ipeak + c3) - N) / 2 / N;
+    freq += e->tune[0];
+    e->mf_value = freq;
+    return QK_OK;
+}
+
 // run one chain over `nlist` receivers; `input` is the stream feeding stage.in == -1
 static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_list, int nlist, hipStream_t cs)
 {
@@ -1617,6 +1739,16 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         }
         }
         if (st.out == c.shared && !st.out_after) c.shared_n1 = out.n;     // the first user's samples of this block are in
+        if (st.measure_div > 0 && out.n > 0 && d_list && !c.members.empty() && c.members[0] == 0) {
+            // measure_audio: bank 0 only (quisk.c:1787-1790, 1873-1876, 1901-1904, 1980-1985, 2015-2018)
+            hipLaunchKernelGGL(k_measure_sum, dim3(1), dim3(256), 0, cs, out.view(), out.planes, out.n, e->d_ma);
+            e->ma_count += out.n;
+            const double fsr = (double)(e->decim_srate / st.measure_div);
+            if ((double)e->ma_count >= fsr * e->ma_time) {
+                hipLaunchKernelGGL(k_measure_close, dim3(1), dim3(1), 0, cs, e->d_ma, (double)e->ma_count);
+                e->ma_count = 0;
+            }
+        }
         if (st.hook && out.n > 0) {
             const int rate = e->decim_srate / st.hook_div;
             const bool cw = &c == &e->cls_chain[CL_CW];
@@ -1628,6 +1760,10 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
                 SsbSquelchArgs sa{out.view(), out.n, rate, e->ssb_sq_level, d_list, e->d_bw, e->d_ssb_carry, e->d_ssb_state,
                                   e->d_sq_flag + (e->pipe_blocks & 1) * e->nrx, e->d_tw4096};
                 hipLaunchKernelGGL(k_ssb_squelch, dim3(nlist), dim3(256), 0, cs, sa);
+            }
+            if (st.hook == 1 && &c == &e->cls_chain[CL_SSB] && !c.members.empty() && c.members[0] == 0 && e->mode[0] == QK_LSB) {
+                int rca = audio_graph_block(e, out, e->ssb_sq_enabled ? SSQ_N : 0, cs);     // LSB only (quisk.c:1835)
+                if (rca != QK_OK) return rca;
             }
         }
     }
@@ -1722,6 +1858,26 @@ static const double2 *dc_and_inversion(qk_engine *e, const double2 *x, int n)
 
 static const double2 *condition_input(qk_engine *e, const double2 *x, int n)
 {
+    if (e->tone_freq != 0 && e->d_tone_tab) {
+        // DCremove (in the sound loop, in front of quisk_process_samples), then the tone, then the inversion (quisk.c:2311-2320)
+        const int inv = e->invert;
+        e->invert = 0;
+        x = dc_and_inversion(e, x, n);
+        e->invert = inv;
+        const int nA = e->nA;
+        ToneArgs a{};
+        a.x = x; a.y = e->d_tone_buf; a.n = n; a.invert = inv;
+        const int md = e->nrx > 0 ? e->mode[0] : QK_USB;                       // rxMode
+        a.kind = md == QK_AM ? 1 : (md == QK_FM || md == QK_DGT_FM) ? 2 : 0;
+        a.vt = MixTables{e->d_tone_tab, e->d_tone_tab + nA, e->d_tone_tab + nA + 64, nullptr, nullptr, nA};
+        a.at = MixTables{e->d_tone_tab + nA + 128, e->d_tone_tab + 2 * nA + 128, e->d_tone_tab + 2 * nA + 192, nullptr, nullptr, nA};
+        a.st_in = e->d_tone_state[e->tone_pp]; a.st_out = e->d_tone_state[e->tone_pp ^ 1];
+        hipLaunchKernelGGL(k_add_tone, dim3((n + 255) / 256), dim3(256), 0, e->fe_stream, a);
+        e->tone_pp ^= 1;
+        x = e->d_tone_buf;
+        if (e->nb_level > 0) x = noise_blanker(e, x, n);
+        return x;
+    }
     x = dc_and_inversion(e, x, n);
     if (e->nb_level > 0) x = noise_blanker(e, x, n);
     return x;
@@ -1856,6 +2012,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     int rc = run_chain(e, F, F.streams[0], nullptr, e->nrx, e->stream);
     if (rc != QK_OK) return rc;
     const Stream &dec = F.streams[F.aud];
+    if (e->mf_mode > 0 && dec.n > 0) { rc = measure_freq_block(e, dec); if (rc != QK_OK) return rc; }      // quisk.c:2400-2401
     // ---- per class: demodulate and audio chain.  The classes are independent of each other and each is a string of a
     //      dozen short, launch-latency-bound kernels: with more than one class present they go down two lanes, the main
     //      stream and the apply stream (idle at this point of the block, and a stream of its own would share a hardware
@@ -2041,6 +2198,11 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         TailArgs ta{}; ta.count = 0; ta.rx_list = nullptr;
         add_tails(ta, F, 0);        // stream 0 is carried by the head copy
         if (ta.count) hipLaunchKernelGGL(k_save_tails, dim3(ta.count, 2, e->nrx), dim3(256), 0, e->stream, ta);
+        if (e->mf_mode > 0 && e->mf_chain.built) {
+            TailArgs tm{}; tm.count = 0; tm.rx_list = nullptr;
+            add_tails(tm, e->mf_chain, -1);
+            if (tm.count) hipLaunchKernelGGL(k_save_tails, dim3(tm.count, 2, 1), dim3(256), 0, e->stream, tm);
+        }
         // the play streams' tails go into the twin buffers, which the previous block's AGC pass may still be reading
         if (e->agc_pending) HIPCHECK(hipStreamWaitEvent(e->stream, e->ev_agc[par ^ 1], 0));
         for (int cl = 0; cl < CL_COUNT; cl++) {
@@ -2160,6 +2322,12 @@ void qk_destroy(qk_engine *e)
     for (void *p : {(void *)e->d_ssb_carry, (void *)e->d_ssb_state, (void *)e->d_bw, (void *)e->d_notch_on, (void *)e->d_notch}) if (p) hipFree(p);
     for (auto &r : e->routes) for (auto &q : r.fifo) for (double *p : q) if (p) hipFree(p);
     for (double *p : e->d_obj) if (p) hipFree(p);
+    for (void *p : {(void *)e->d_tone_tab, (void *)e->d_tone_state[0], (void *)e->d_tone_state[1], (void *)e->d_tone_buf,
+                    (void *)e->d_gen_in, (void *)e->d_gen_out}) if (p) hipFree(p);
+    any_free(e->gen); any_free(e->mf_fft); any_free(e->ag_fft);
+    free_chain(e->mf_chain);
+    for (void *p : {(void *)e->d_ma, (void *)e->d_mf_frame, (void *)e->d_mf_X, (void *)e->d_mf_avg, (void *)e->d_ag_frame, (void *)e->d_ag_X,
+                    (void *)e->d_ag_avg}) if (p) hipFree(p);
     for (void *p : {(void *)e->d_scan_avg, (void *)e->d_raw_rows, (void *)e->d_rfb_x[0], (void *)e->d_rfb_x[1], (void *)e->d_rfb_x[2], (void *)e->d_rfb_y, (void *)e->d_rfb_t}) if (p) hipFree(p);
     for (auto &ev : e->ev_pool) if (ev) hipEventDestroy(ev);
     if (e->agc_stream) { hipStreamSynchronize(e->agc_stream); hipStreamDestroy(e->agc_stream); }
@@ -2261,6 +2429,7 @@ int qk_set_filters(qk_engine *e, int rx, const double *fi, const double *fq, int
             HIPCHECK(hipMemcpy(e->d_taps_f + (size_t)rx * 2 * e->tap_cap, hf.data(), sizeof(float) * hf.size(), hipMemcpyHostToDevice));
         }
     }
+    if (rx == 0) { e->f0_i.assign(fi, fi + n); e->f0_q.assign(fq, fq + n); }
     e->ntaps[rx] = n; e->bandwidth[rx] = bandwidth; e->start_offset[rx] = start_offset;
     HIPCHECK(hipMemcpy(e->d_bw + rx, &bandwidth, sizeof(int), hipMemcpyHostToDevice));
     { int rcn = upload_ntaps(e, rx); if (rcn != QK_OK) return rcn; }
@@ -2928,6 +3097,175 @@ int qk_rx_filter_block(qk_engine *e, int rx, int bank, const double *in_host, do
     HIPCHECK(hipGetLastError());
     if (nt <= 0) memcpy(out_host, in_host, sizeof(double2) * n);       // sizeFilter == 0: the sample passes (quisk.c:1164-1165)
     return n;
+}
+
+int qk_add_tone(qk_engine *e, int freq_hz)
+{   // add_tone, quisk.c:3022-3034: testtonePhase = cexp(I 2 pi freq / rate), 0 = off.  The vectors are statics of AddTestTone
+    // (testtoneVector = 21474836.47, audioVector = 1, quisk.c:1197-1198): they carry on from one tone to the next
+    ENGINE_ENTER(e);
+    SYNC_ALL(e);
+    const int nA = (e->cfg.max_block >> 12) + 2;
+    if (e->nrx == 0) e->nA = nA;
+    if (freq_hz != 0 && !e->d_tone_tab) {
+        HIPCHECK(hipMalloc(&e->d_tone_tab, sizeof(double2) * (size_t)(2 * nA + 256)));
+        HIPCHECK(hipMalloc(&e->d_tone_buf, sizeof(double2) * (size_t)e->cfg.max_block));
+        const double2 init[2] = {make_double2(21474836.47, 0.0), make_double2(1.0, 0.0)};
+        for (int i = 0; i < 2; i++) {
+            HIPCHECK(hipMalloc(&e->d_tone_state[i], sizeof(double2) * 2));
+            HIPCHECK(hipMemcpy(e->d_tone_state[i], init, sizeof init, hipMemcpyHostToDevice));
+        }
+        // the audio vector's step: cexp(I 2 pi 1000 / rate) (quisk.c:1211, 1221)
+        double pre, pim;
+        qk_phase_step(-1000, e->cfg.sample_rate, &pre, &pim);
+        std::vector<double> C(128), B(128), A((size_t)2 * nA);
+        qk_phase_tables(pre, pim, C.data(), B.data(), A.data(), nA);
+        HIPCHECK(hipMemcpy(e->d_tone_tab + nA + 128, A.data(), sizeof(double) * 2 * nA, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(e->d_tone_tab + 2 * nA + 128, B.data(), sizeof(double) * 128, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(e->d_tone_tab + 2 * nA + 192, C.data(), sizeof(double) * 128, hipMemcpyHostToDevice));
+    }
+    if (freq_hz != 0) {
+        double pre, pim;
+        qk_phase_step(-freq_hz, e->cfg.sample_rate, &pre, &pim);       // = cexp((I * 2.0 * M_PI * freq) / rate), quisk.c:3030
+        std::vector<double> C(128), B(128), A((size_t)2 * nA);
+        qk_phase_tables(pre, pim, C.data(), B.data(), A.data(), nA);
+        HIPCHECK(hipMemcpy(e->d_tone_tab, A.data(), sizeof(double) * 2 * nA, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(e->d_tone_tab + nA, B.data(), sizeof(double) * 128, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(e->d_tone_tab + nA + 64, C.data(), sizeof(double) * 128, hipMemcpyHostToDevice));
+    }
+    e->tone_freq = freq_hz;
+    return QK_OK;
+}
+
+// one transform of n points through the engine's FFT: forward, or FFTW's unnormalised backward transform as
+// conj(forward(conj(x))).  in / out: n interleaved complex doubles in host memory.
+static int fft_any_host(qk_engine *e, const double *in, int n, int inverse, double *out)
+{
+    if (n == 1) { out[0] = in[0]; out[1] = in[1]; return QK_OK; }
+    if (e->gen_n != n) {
+        HIPCHECK(hipStreamSynchronize(e->fe_stream));
+        any_free(e->gen);
+        for (void *p : {(void *)e->d_gen_in, (void *)e->d_gen_out}) if (p) hipFree(p);
+        e->d_gen_in = e->d_gen_out = nullptr; e->gen_n = 0;
+        int rc = any_init(e, e->gen, n, nullptr);
+        if (rc != QK_OK) return rc;
+        HIPCHECK(hipMalloc(&e->d_gen_in, sizeof(double2) * n));
+        HIPCHECK(hipMalloc(&e->d_gen_out, sizeof(double2) * n));
+        e->gen_n = n;
+    }
+    std::vector<double> tmp;
+    const double *src = in;
+    if (inverse) {
+        tmp.assign(in, in + 2 * (size_t)n);
+        for (int i = 0; i < n; i++) tmp[2 * i + 1] = -tmp[2 * i + 1];
+        src = tmp.data();
+    }
+    hipStream_t st = e->fe_stream;
+    HIPCHECK(hipMemcpyAsync(e->d_gen_in, src, sizeof(double2) * n, hipMemcpyHostToDevice, st));
+    any_run(e, e->gen, st, e->d_gen_in, nullptr, e->d_gen_out);
+    HIPCHECK(hipMemcpyAsync(out, e->d_gen_out, sizeof(double2) * n, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    HIPCHECK(hipGetLastError());
+    if (inverse) for (int i = 0; i < n; i++) out[2 * i + 1] = -out[2 * i + 1];
+    return QK_OK;
+}
+
+int qk_measure_audio(qk_engine *e, int time, double *value)
+{   // measure_audio, quisk.c:3011-3020: time > 0 sets the averaging time in seconds; returns measured_audio (RMS of receiver 0's
+    // detected audio over that time, in millionths of full scale)
+    ENGINE_ENTER(e);
+    if (time > 0) e->ma_time = time;
+    double v[2] = {0, 0};
+    if (e->d_ma) {
+        HIPCHECK(hipStreamSynchronize(e->stream));
+        if (e->apply_stream) HIPCHECK(hipStreamSynchronize(e->apply_stream));
+        HIPCHECK(hipStreamSynchronize(e->agc_stream));
+        HIPCHECK(hipMemcpy(v, e->d_ma, sizeof v, hipMemcpyDeviceToHost));
+    }
+    if (value) *value = v[1];
+    return QK_OK;
+}
+
+int qk_measure_frequency(qk_engine *e, int mode, double *value)
+{   // measure_frequency, quisk.c:3000-3009: mode >= 0 sets measure_freq_mode (0 = off; a measurement every mode / 2 frames of two
+    // seconds), mode < 0 only reads; returns measured_frequency in Hz from the centre of the stream
+    ENGINE_ENTER(e);
+    if (mode >= 0 && mode != e->mf_mode) { SYNC_ALL(e); e->mf_mode = mode; }
+    if (value) *value = e->mf_value;
+    return QK_OK;
+}
+
+int qk_get_audio_graph(qk_engine *e, double *out, int data_width)
+{   // get_audio_graph, quisk.c:966-991: 1 and data_width dB values when a graph is ready (it is then cleared), else 0
+    ENGINE_ENTER(e);
+    if (!out || data_width != e->cfg.data_width) return fail(QK_EINVAL, "data_width differs from the engine's");
+    if (!e->ag_ready) return 0;
+    const int N = e->ag_N;
+    SYNC_ALL(e);
+    HIPCHECK(hipMemcpy(out, e->d_ag_avg, sizeof(double) * N, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemset(e->d_ag_avg, 0, sizeof(double) * N));
+    for (int i = 0; i < N; i++) out[i] = 20.0 * log10(out[i] < 1E-10 ? 1E-10 : out[i]);
+    e->ag_ready = 0;
+    return 1;
+}
+
+int qk_fft_any(qk_engine *e, const double *in_host, int n, int inverse, double *out_host)
+{
+    ENGINE_ENTER(e);
+    if (!in_host || !out_host || n < 1 || n > (1 << 22)) return fail(QK_EINVAL, "bad transform arguments");
+    return fft_any_host(e, in_host, n, inverse, out_host);
+}
+
+int qk_get_filter(qk_engine *e, double *out, int data_width)
+{   // get_filter, quisk.c:4761-4848: the response of receiver 0's band-pass (filter slot 0) to a comb of cosines at every bin
+    // frequency up to data_width / 2 - 10, through the reference's ring in its tap order, the first data_width entries of the
+    // DISPLAY window (fft_window has fft_size entries, quisk.c:4816-4817), a data_width-point transform, 20 log10(|X| / width)
+    ENGINE_ENTER(e);
+    const int W = data_width, N = (int)e->f0_i.size();
+    if (!out || W < 2 || W > (1 << 20)) return fail(QK_EINVAL, "bad get_filter arguments");
+    if (e->cfg.fft_size < W) return fail(QK_EINVAL, "get_filter needs the display window (engine made with fft_size >= data_width)");
+    const int T = W + N;
+    std::vector<double> avg((size_t)T, 0.5);                          // Value for freq == 0
+    for (int freq = 1; freq < W / 2.0 - 10.0; freq++) {
+        const double delta = 2 * M_PI / W * freq;
+        double phase = 0;
+        for (int t = 0; t < T; t++) {
+            avg[t] += cos(phase);
+            phase += delta;
+            if (phase > 2 * M_PI) phase -= 2 * M_PI;
+        }
+    }
+    std::vector<double> bufI((size_t)std::max(N, 1), 0.0), bufQ((size_t)std::max(N, 1), 0.0), sam((size_t)2 * W, 0.0), X((size_t)2 * W);
+    int nidx = 0;
+    for (int t = 0; t < T; t++) {
+        double accI = 0, accQ = 0;
+        if (N > 0) {
+            bufI[nidx] = avg[t]; bufQ[nidx] = avg[t];
+            int j = nidx;
+            for (int k = 0; k < N; k++) {
+                accI += bufI[j] * e->f0_i[k];
+                accQ += bufQ[j] * e->f0_q[k];
+                if (++j >= N) j = 0;
+            }
+            if (++nidx >= N) nidx = 0;
+        }
+        if (t >= N) { sam[2 * (size_t)(t - N)] = accI; sam[2 * (size_t)(t - N) + 1] = accQ; }
+    }
+    const int F = e->cfg.fft_size;
+    for (int i = 0; i < W; i++) {
+        const double w = 0.5 + 0.5 * cos(2. * M_PI * (i - F / 2) / F);     // fft_window[i], quisk.c:5091-5096
+        sam[2 * (size_t)i] *= w; sam[2 * (size_t)i + 1] *= w;
+    }
+    int rc = fft_any_host(e, sam.data(), W, 0, X.data());
+    if (rc != QK_OK) return rc;
+    const double scale = 1. / W;
+    int i = 0;
+    auto db = [&](int k) {
+        const double a = hypot(X[2 * (size_t)k], X[2 * (size_t)k + 1]) * scale;
+        return 20.0 * (a <= 1e-7 ? -7.0 : log10(a));
+    };
+    for (int k = W / 2; k < W; k++, i++) out[i] = db(k);
+    for (int k = 0; k < W / 2; k++, i++) out[i] = db(k);
+    return QK_OK;
 }
 
 int qk_get_filter_rate(int sample_rate, int mode, int bandwidth) { return filter_rate(sample_rate, mode, bandwidth); }

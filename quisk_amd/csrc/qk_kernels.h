@@ -1927,6 +1927,77 @@ __global__ __launch_bounds__(256) void k_route_combine(const double2 *left, cons
     const bool ml = kill || (mute_l && *mute_l), mr = kill || (mute_r && *mute_r);
     out[i] = make_double2(ml ? 0.0 : left[i].x, mr ? 0.0 : right[i].x);
 }
+// measure_audio (quisk.c:1787-1790, 2015-2018): the running sum of squares of receiver 0's detected audio.  One workgroup,
+// a fixed summation order (the reference adds sample by sample: the sums differ in the last bits).  acc[0] += sum.
+__global__ __launch_bounds__(256) void k_measure_sum(StreamView in, int planes, int n, double *acc)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int pl = 0; pl < planes; pl++) {
+        const double *p = sv_ptr(in, 0, pl);
+        for (int i = threadIdx.x; i < n; i += 256) s += p[i] * p[i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) acc[0] += red[0];
+}
+// ... and its close: measured_audio = sqrt(sum / count) / CLIP32 * 1e6; the sum starts again
+__global__ void k_measure_close(double *acc, double count)
+{
+    acc[1] = sqrt(acc[0] / count) / QK_CLIP32 * 1e6;
+    acc[0] = 0.0;
+}
+// Frames for the audio graph (quisk_calc_audio_graph, quisk.c:903-964) and for measure_freq (quisk.c:4850-4920): `take` samples
+// of receiver 0's stream (plane 1 may be absent: a real stream) go to frame[index ...], each divided by `scale`
+__global__ __launch_bounds__(256) void k_frame_collect(StreamView in, int planes, int first, int take, double2 *frame, int index, double scale)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= take) return;
+    const double re = sv_ptr(in, 0, 0)[first + i] / scale;
+    const double im = planes > 1 ? sv_ptr(in, 0, 1)[first + i] / scale : 0.0;
+    frame[index + i] = make_double2(re, im);
+}
+// magnitudes of a transformed frame added in order of frequency (negative frequencies first; quisk.c:953-957, 4889-4893)
+__global__ __launch_bounds__(256) void k_frame_accum(const double2 *X, int N, double *avg)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    const int h = N / 2, src = k < N - h ? k + h : k - (N - h);
+    avg[k] += hypot(X[src].x, X[src].y);
+}
+// AddTestTone (quisk.c:1194-1229; add_tone, quisk.c:3022-3034): a -40 dBFS complex tone added to the full-rate stream in front
+// of the inversion, the noise blanker and the FFT staging.  testtoneVector and audioVector are never-renormalised recurrences
+// like the mixer's: their values come from the same power tables of the rounded phase steps (qk_phasor.c).
+//   kind 0: x += V;  1 (AM): x += V (1 + Re A);  2 (FM, DGT-FM): x += V cexp(I Re A)       V = v0 p^i, A = a0 q^i
+struct ToneArgs { const double2 *x; double2 *y; int n, kind, invert; MixTables vt, at; const double2 *st_in; double2 *st_out; };
+__global__ __launch_bounds__(256) void k_add_tone(ToneArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    // row 0 of the tables; the vectors at the block's first sample are st_in[0] (tone) and st_in[1] (audio)
+    MixTables vt = a.vt, at = a.at;
+    vt.v0 = a.st_in; at.v0 = a.st_in + 1;
+    if (i == 0) {
+        a.st_out[0] = mix_w(vt, 0, a.n);
+        a.st_out[1] = a.kind ? mix_w(at, 0, a.n) : a.st_in[1];
+    }
+    if (i >= a.n) return;
+    double2 v = mix_w(vt, 0, i);
+    if (a.kind == 1) {
+        const double m = 1.0 + mix_w(at, 0, i).x;
+        v = make_double2(v.x * m, v.y * m);
+    } else if (a.kind == 2) {
+        const double ph = mix_w(at, 0, i).x;
+        v = cmul(v, make_double2(cos(ph), sin(ph)));
+    }
+    double2 s = a.x[i];
+    s = make_double2(s.x + v.x, s.y + v.y);
+    if (a.invert) s.y = -s.y;                      // the inversion comes behind the tone (quisk.c:2311-2320)
+    a.y[i] = s;
+}
 // Mono again behind a stretch of stereo (quisk.c:2495-2501, 2573-2575), while the pair's two planes still differ: the
 // reference's mono sample is complex, d + I d, and runs through the SAME cFracDecim / HalfBand7..9 / Agc1 objects as the pair
 // did -- whose imaginary parts hold the right channel's last samples, and whose AGC ring holds real samples only (the stereo

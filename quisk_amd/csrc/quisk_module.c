@@ -14,6 +14,7 @@
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <complex.h>
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 #include <time.h>
@@ -68,6 +69,7 @@ static struct {
     int rx_mode;
     /* second-receiver routing (quisk.c:2410-2494): split_rxtx 0..4, multirx_play_method 0..2, multirx_play_channel or -1 */
     int split_rxtx, play_method, play_channel, rx_tune, tx_tune, rit_freq, partner_dirty, multirx_state;
+    double adc_level;
     int vfo_screen, vfo_audio;                      /* change_rates, quisk.c:3874-3886 */
     int scan_blocks, scan_rate, scan_vfo0, scan_deltaf; double scan_valid;      /* change_scan, quisk.c:3865-3872 */
     double *f0; int f0_n, f0_bw, f0_off;            /* the taps of filter slot 0, for the split partner */
@@ -607,6 +609,7 @@ static PyObject *get_bandscope(PyObject *self, PyObject *args)
     const int count = qk_get_bandscope(G.qk, clock, zoom, deltaf, G.row, W, &adc);
     if (count < 0) return engine_error();
     if (count == 0) Py_RETURN_NONE;
+    G.adc_level = adc;                                      /* hermes_adc_level, quisk.c:4591 */
     G.bscope_t0 = QuiskTimeSec();
     PyObject *t = PyTuple_New(W);
     for (int i = 0; t && i < W; i++) PyTuple_SET_ITEM(t, i, PyFloat_FromDouble(G.row[i]));
@@ -717,6 +720,147 @@ static PyObject *rx_filter_block(PyObject *self, PyObject *args)
 }
 
 /* Entries outside the receive path: accepted and ignored. */
+/* ---------------------------------------------------------------- diagnostics fed by the path */
+static PyObject *add_tone(PyObject *self, PyObject *args)
+{   /* quisk.c:3022-3034 */
+    int freq;
+    if (!PyArg_ParseTuple(args, "i", &freq)) return NULL;
+    if (!need_engine()) return NULL;
+    if (qk_add_tone(G.qk, freq) != QK_OK) return engine_error();
+    Py_RETURN_NONE;
+}
+static PyObject *float_tuple(const double *v, int n)
+{
+    PyObject *t = PyTuple_New(n);
+    if (!t) return NULL;
+    for (int i = 0; i < n; i++) PyTuple_SET_ITEM(t, i, PyFloat_FromDouble(v[i]));
+    return t;
+}
+static PyObject *get_filter(PyObject *self, PyObject *args)
+{   /* quisk.c:4761-4848: a tuple of data_width dB values */
+    if (!PyArg_ParseTuple(args, "")) return NULL;
+    if (!need_engine()) return NULL;
+    double *v = malloc(sizeof(double) * (size_t)G.data_width);
+    if (!v) return PyErr_NoMemory();
+    if (qk_get_filter(G.qk, v, G.data_width) != QK_OK) { free(v); return engine_error(); }
+    PyObject *t = float_tuple(v, G.data_width);
+    free(v);
+    return t;
+}
+static PyObject *get_tx_filter(PyObject *self, PyObject *args)
+{   /* microphone.c:719-807: the transmit chain is off the path; the reference's shape (data_width dB values) at its floor */
+    if (!PyArg_ParseTuple(args, "")) return NULL;
+    PyObject *t = PyTuple_New(G.data_width > 0 ? G.data_width : 0);
+    if (!t) return NULL;
+    for (int i = 0; i < G.data_width; i++) PyTuple_SET_ITEM(t, i, PyFloat_FromDouble(-140.0));
+    return t;
+}
+static PyObject *get_audio_graph(PyObject *self, PyObject *args)
+{   /* quisk.c:966-991: None until a graph is ready */
+    if (!PyArg_ParseTuple(args, "")) return NULL;
+    if (!need_engine()) return NULL;
+    double *v = malloc(sizeof(double) * (size_t)G.data_width);
+    if (!v) return PyErr_NoMemory();
+    const int got = qk_get_audio_graph(G.qk, v, G.data_width);
+    if (got < 0) { free(v); return engine_error(); }
+    PyObject *t = got ? float_tuple(v, G.data_width) : (Py_INCREF(Py_None), Py_None);
+    free(v);
+    return t;
+}
+static PyObject *measure_frequency(PyObject *self, PyObject *args)
+{   /* quisk.c:3000-3009 */
+    int mode;
+    double v = 0;
+    if (!PyArg_ParseTuple(args, "i", &mode)) return NULL;
+    if (!need_engine()) return NULL;
+    if (qk_measure_frequency(G.qk, mode, &v) != QK_OK) return engine_error();
+    return PyFloat_FromDouble(v);
+}
+static PyObject *measure_audio(PyObject *self, PyObject *args)
+{   /* quisk.c:3011-3020 */
+    int time;
+    double v = 0;
+    if (!PyArg_ParseTuple(args, "i", &time)) return NULL;
+    if (!need_engine()) return NULL;
+    if (qk_measure_audio(G.qk, time, &v) != QK_OK) return engine_error();
+    return PyFloat_FromDouble(v);
+}
+static PyObject *xdft(PyObject *seq, int inverse, int window)
+{   /* Xdft, quisk.c:4922-5014: the sequence is in order of frequency with zero at index (size - 1) / 2; Blackman window on the
+     * frequency side of an inverse / the time side of a forward transform; the inverse is normalised by 1 / N; returns a list */
+    if (PySequence_Check(seq) != 1) { PyErr_SetString(QuiskError, "DFT input data is not a sequence"); return NULL; }
+    const Py_ssize_t size = PySequence_Size(seq);
+    if (size <= 0) return PyTuple_New(0);
+    if (!need_engine()) return NULL;
+    double *x = malloc(sizeof(double) * 4 * (size_t)size), *y = x ? x + 2 * size : NULL;
+    if (!x) return PyErr_NoMemory();
+    Py_ssize_t j = (size - 1) / 2;
+    for (Py_ssize_t i = 0; i < size; i++) {
+        PyObject *o = PySequence_GetItem(seq, j);
+        if (o && PyComplex_Check(o)) { Py_complex c = PyComplex_AsCComplex(o); x[2 * i] = c.real; x[2 * i + 1] = c.imag; }
+        else if (o && PyFloat_Check(o)) { x[2 * i] = PyFloat_AsDouble(o); x[2 * i + 1] = 0; }
+        else if (o && PyLong_Check(o)) { x[2 * i] = (double)PyLong_AsLong(o); x[2 * i + 1] = 0; }
+        else { Py_XDECREF(o); free(x); PyErr_SetString(QuiskError, "DFT input data is not a complex/float/int number"); return NULL; }
+        Py_DECREF(o);
+        if (++j >= size) j = 0;
+    }
+    double *w = NULL;
+    if (window) {
+        w = malloc(sizeof(double) * (size_t)(size + 1));
+        if (!w) { free(x); return PyErr_NoMemory(); }
+        for (Py_ssize_t i = 0; i <= size / 2; i++)
+            w[i] = w[size - i] = 0.42 + 0.50 * cos(2. * M_PI * i / size) + 0.08 * cos(4. * M_PI * i / size);
+    }
+    if (!inverse && w) for (Py_ssize_t i = 0; i < size; i++) { x[2 * i] *= w[i]; x[2 * i + 1] *= w[i]; }
+    if (qk_fft_any(G.qk, x, (int)size, inverse, y) != QK_OK) { free(x); free(w); return engine_error(); }
+    if (inverse) for (Py_ssize_t i = 0; i < size; i++) {
+        if (w) { const double f = w[i] / size; y[2 * i] *= f; y[2 * i + 1] *= f; }
+        else { y[2 * i] /= size; y[2 * i + 1] /= size; }
+    }
+    PyObject *out = PyList_New(size);
+    j = (size - 1) / 2;
+    for (Py_ssize_t i = 0; out && i < size; i++) {
+        PyList_SET_ITEM(out, j, PyComplex_FromDoubles(y[2 * i], y[2 * i + 1]));
+        if (++j >= size) j = 0;
+    }
+    free(x); free(w);
+    return out;
+}
+static PyObject *dft(PyObject *self, PyObject *args)
+{
+    PyObject *seq; int window = 0;
+    if (!PyArg_ParseTuple(args, "O|i", &seq, &window)) return NULL;
+    return xdft(seq, 0, window);
+}
+static PyObject *idft(PyObject *self, PyObject *args)
+{
+    PyObject *seq; int window = 0;
+    if (!PyArg_ParseTuple(args, "O|i", &seq, &window)) return NULL;
+    return xdft(seq, 1, window);
+}
+/* Entries of the reference's table that are off the receive path (sound cards, Hermes control, FreeDV): callable with the
+ * reference's arity, returning the reference's shapes with nothing in them */
+static PyObject *no_args_none(PyObject *self, PyObject *args) { if (!PyArg_ParseTuple(args, "")) return NULL; Py_RETURN_NONE; }
+static PyObject *sound_devices(PyObject *self, PyObject *args)
+{   /* sound_alsa.c:496: (capture names, playback names) */
+    if (!PyArg_ParseTuple(args, "")) return NULL;
+    return Py_BuildValue("([][])");
+}
+static PyObject *sound_errors(PyObject *self, PyObject *args) { if (!PyArg_ParseTuple(args, "")) return NULL; return PyList_New(0); }   /* sound.c:1284 */
+static PyObject *ip_interfaces(PyObject *self, PyObject *args) { if (!PyArg_ParseTuple(args, "")) return NULL; return PyList_New(0); }  /* quisk.c:4062 */
+static PyObject *get_hermes_adc(PyObject *self, PyObject *args)
+{   /* quisk.c:2751-2756: hermes_adc_level, the largest bandscope sample of the last release */
+    if (!PyArg_ParseTuple(args, "")) return NULL;
+    return PyFloat_FromDouble(G.adc_level);
+}
+static PyObject *get_hermes_TFRC(PyObject *self, PyObject *args) { if (!PyArg_ParseTuple(args, "")) return NULL; return Py_BuildValue("dddd", 0.0, 0.0, 0.0, 0.0); }  /* quisk.c:2968 */
+static PyObject *get_hermeslite_writepointer(PyObject *self, PyObject *args) { if (!PyArg_ParseTuple(args, "")) return NULL; return Py_BuildValue("I", 0u); }        /* quisk.c:3988 */
+static PyObject *get_hermeslite_response(PyObject *self, PyObject *args) { static const char z[5] = {0}; if (!PyArg_ParseTuple(args, "")) return NULL; return PyByteArray_FromStringAndSize(z, 5); }   /* quisk.c:3995 */
+static PyObject *hermes_to_pc(PyObject *self, PyObject *args) { static const char z[20] = {0}; if (!PyArg_ParseTuple(args, "")) return NULL; return PyByteArray_FromStringAndSize(z, 20); }            /* quisk.c:4011 */
+static PyObject *freedv_get_snr(PyObject *self, PyObject *args) { if (!PyArg_ParseTuple(args, "")) return NULL; return PyFloat_FromDouble(0.0); }       /* freedv.c:532 */
+static PyObject *freedv_get_version(PyObject *self, PyObject *args) { if (!PyArg_ParseTuple(args, "")) return NULL; return PyLong_FromLong(-1); }      /* freedv.c:62, 543: no codec library */
+static PyObject *freedv_get_rx_char(PyObject *self, PyObject *args) { if (!PyArg_ParseTuple(args, "")) return NULL; return PyUnicode_FromString(""); } /* freedv.c:379 */
+
 static PyObject *inert(PyObject *self, PyObject *args, PyObject *kw) { Py_RETURN_NONE; }
 static PyObject *inert_zero(PyObject *self, PyObject *args, PyObject *kw) { return PyLong_FromLong(0); }
 #define INERT(name) { name, (PyCFunction)inert, METH_VARARGS | METH_KEYWORDS, "Outside the receive path: accepted and ignored." }
@@ -763,7 +907,30 @@ static PyMethodDef QuiskMethods[] = {
     { "is_key_down", (PyCFunction)inert_zero, METH_VARARGS | METH_KEYWORDS, "Receive only: the key is up." },
     { "get_hardware_ptt", (PyCFunction)inert_zero, METH_VARARGS | METH_KEYWORDS, "Receive only." },
     { "is_vox", (PyCFunction)inert_zero, METH_VARARGS | METH_KEYWORDS, "Receive only." },
-    INERT("set_volume"), INERT("set_enable_bandscope"), INERT("add_tone"), INERT("set_spot_level"), INERT("set_imd_level"),
+    { "add_tone", add_tone, METH_VARARGS, "Add a test tone to the data." },
+    { "get_filter", get_filter, METH_VARARGS, "Return the frequency response of the receive filter." },
+    { "get_tx_filter", get_tx_filter, METH_VARARGS, "Return the frequency response of the transmit filter." },
+    { "get_audio_graph", get_audio_graph, METH_VARARGS, "Return a tuple of the audio graph data." },
+    { "measure_frequency", measure_frequency, METH_VARARGS, "Set the method, return the measured frequency." },
+    { "measure_audio", measure_audio, METH_VARARGS, "Set the method, return the measured audio voltage." },
+    { "dft", dft, METH_VARARGS, "Calculate the discrete Fourier transform." },
+    { "idft", idft, METH_VARARGS, "Calculate the inverse discrete Fourier transform." },
+    { "sound_devices", sound_devices, METH_VARARGS, "Return a list of available sound device names." },
+    { "pa_sound_devices", sound_devices, METH_VARARGS, "Return a list of available PulseAudio device names." },
+    { "sound_errors", sound_errors, METH_VARARGS, "Return a list of text strings with sound devices and error counts" },
+    { "ip_interfaces", ip_interfaces, METH_VARARGS, "Return a list of interface data." },
+    { "get_hermes_adc", get_hermes_adc, METH_VARARGS, "Return the ADC peak level." },
+    { "get_hermes_TFRC", get_hermes_TFRC, METH_VARARGS, "Return the temperature, forward and reverse power and PA current." },
+    { "get_hermeslite_writepointer", get_hermeslite_writepointer, METH_VARARGS, "Return the Hermes-Lite write pointer." },
+    { "get_hermeslite_response", get_hermeslite_response, METH_VARARGS, "Return the Hermes-Lite response array." },
+    { "hermes_to_pc", hermes_to_pc, METH_VARARGS, "Get the Hermes response C0 to C4 for C0 == 0, 8, 16, 24." },
+    { "test_1", no_args_none, METH_VARARGS, "Test 1 function." },
+    { "test_2", no_args_none, METH_VARARGS, "Test 2 function." },
+    { "test_3", no_args_none, METH_VARARGS, "Test 3 function." },
+    { "freedv_get_snr", freedv_get_snr, METH_VARARGS, "Return the signal to noise ratio in dB." },
+    { "freedv_get_version", freedv_get_version, METH_VARARGS, "Return the codec2 API version." },
+    { "freedv_get_rx_char", freedv_get_rx_char, METH_VARARGS, "Get text characters received from freedv." },
+    INERT("set_volume"), INERT("set_enable_bandscope"), INERT("set_spot_level"), INERT("set_imd_level"),
     INERT("set_key_down"), INERT("set_PTT"), INERT("set_ctcss"), INERT("set_tx_audio"), INERT("set_record_state"), INERT("set_file_name"),
     INERT("set_transmit_mode"), INERT("set_fdx"), INERT("set_sample_bytes"), INERT("change_rate"),
     INERT("open_sound"), INERT("open_key"), INERT("open_rx_udp"), INERT("close_rx_udp"),

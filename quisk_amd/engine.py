@@ -102,6 +102,12 @@ def lib():
     L.qk_dD_out_block.argtypes = [vp, C.c_int, vp, C.c_int, vp]
     L.qk_process_hermes.argtypes = [vp, vp, C.c_int, C.c_int, vp, ip, ip]
     L.quisk_cCplxSampleFilter_noalloc.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip, vp]
+    L.qk_add_tone.argtypes = [vp, C.c_int]
+    L.qk_get_filter.argtypes = [vp, vp, C.c_int]
+    L.qk_measure_audio.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    L.qk_measure_frequency.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    L.qk_get_audio_graph.argtypes = [vp, vp, C.c_int]
+    L.qk_fft_any.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     _lib = L
     return L
 
@@ -215,6 +221,39 @@ class Engine:
     def route_tap(self, rx):
         """(debug) the pair of receiver rx's live stereo route in front of its two AGCs: [2][count], left and right"""
         return self.tap(TAP_ROUTE, rx, planes=2, cap=self.out_cap + 32768)
+
+    def add_tone(self, freq_hz):
+        """add_tone (quisk.c:3022-3034): the test tone of AddTestTone at freq_hz from the centre; 0 = off."""
+        _check(self.L.qk_add_tone(self.h, int(freq_hz)))
+
+    def get_filter(self, data_width):
+        """get_filter (quisk.c:4761-4848): frequency response of receiver 0's band-pass, dB, negative frequencies first."""
+        out = np.zeros(int(data_width), dtype=np.float64)
+        _check(self.L.qk_get_filter(self.h, out.ctypes.data, int(data_width)))
+        return out
+
+    def measure_audio(self, time):
+        v = C.c_double(0.0)
+        _check(self.L.qk_measure_audio(self.h, int(time), C.byref(v)))
+        return v.value
+
+    def measure_frequency(self, mode):
+        v = C.c_double(0.0)
+        _check(self.L.qk_measure_frequency(self.h, int(mode), C.byref(v)))
+        return v.value
+
+    def get_audio_graph(self):
+        """get_audio_graph (quisk.c:966-991): data_width dB values, or None when no graph is ready."""
+        out = np.zeros(self.data_width, dtype=np.float64)
+        got = _check(self.L.qk_get_audio_graph(self.h, out.ctypes.data, self.data_width))
+        return out if got else None
+
+    def fft_any(self, x, inverse=False):
+        """the transform behind dft / idft (quisk.c:4922-5014): forward, or FFTW's unnormalised backward"""
+        x = np.ascontiguousarray(x, dtype=np.complex128)
+        out = np.empty_like(x)
+        _check(self.L.qk_fft_any(self.h, x.ctypes.data, len(x), int(bool(inverse)), out.ctypes.data))
+        return out
 
     def key_up(self):
         """The key went up: the 5 ms envelope of quisk.c:2602-2612 starts with the next block."""

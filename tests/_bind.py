@@ -158,6 +158,20 @@ def oracle():
     L.qko_graph_change_scan.argtypes = [P(OGraph), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
     L.qko_graph_release.argtypes = [P(OGraph), C.c_double, C.c_double, ddp, P(C.c_double)]
     L.qko_buffer2chan.argtypes = [P(OB2C), ddp, C.c_int, ddp, C.c_int]
+    L.qko_add_test_tone.argtypes = [C.c_void_p, cdp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.qko_tone_init.argtypes = [C.c_void_p]
+    L.qko_get_filter.argtypes = [ddp, ddp, C.c_int, C.c_int, C.c_int, ddp]
+    L.qko_mfreq_new.restype = C.c_void_p
+    L.qko_mfreq_delete.argtypes = [C.c_void_p]
+    L.qko_measure_freq.argtypes = [C.c_void_p, cdp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.qko_measure_freq.restype = C.c_double
+    L.qko_audio_graph_new.restype = C.c_void_p
+    L.qko_audio_graph_new.argtypes = [C.c_int]
+    L.qko_audio_graph_delete.argtypes = [C.c_void_p]
+    L.qko_audio_graph_get.argtypes = [C.c_void_p, ddp]
+    L.qko_rx_set_audio_graph.argtypes = [C.c_void_p, C.c_void_p]
+    L.qko_rx_measure_audio.argtypes = [C.c_void_p, C.c_int]
+    L.qko_rx_measure_audio.restype = C.c_double
     L.qko_pair_new.restype = C.c_void_p
     L.qko_pair_delete.argtypes = [C.c_void_p]
     L.qko_pair_reset_fifos.argtypes = [C.c_void_p]

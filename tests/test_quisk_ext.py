@@ -264,3 +264,49 @@ def test_change_rates_and_change_scan_through_the_extension():
     QS.change_scan(0, fs, 0.84, 0, 0)
     orx.close(); og.close()
     QS.close_sound()
+
+
+@pytest.mark.gpu
+def test_diagnostics_through_the_extension():
+    """dft / idft (Xdft, quisk.c:4922-5014: order of frequency, zero at index (size - 1) / 2, Blackman window, 1 / N on the
+    inverse), get_filter, get_tx_filter, measure_audio, measure_frequency, get_audio_graph, add_tone: the entries that
+    quisk.py calls while it runs (quisk.py:3204, 4178-4194, 4693, 4702, 5277, 5915), with the reference's return types."""
+    fs, W = 48000, 256
+    QS.record_app(None, _conf(), W, W, 1024, 64, fs, 0)
+    QS.set_params(rx_bytes=4, rx_endian=0)
+    fi, fq, bw, off = rx_filter(fs, 3)
+    QS.set_rx_mode(3); QS.set_filters(list(fi), list(fq), bw, off, 0)
+    rng = np.random.default_rng(2)
+    for size in (8, 31, 1000):
+        x = rng.standard_normal(size) + 1j * rng.standard_normal(size)
+        j0 = (size - 1) // 2
+        X = QS.dft(list(x))
+        assert isinstance(X, list) and len(X) == size
+        want = np.roll(np.fft.fft(np.roll(x, -j0)), j0)
+        assert np.max(np.abs(np.array(X) - want)) < 1e-10
+        y = QS.idft(X)
+        assert np.max(np.abs(np.array(y) - x)) < 1e-12
+        w = np.array([0.42 + 0.5 * np.cos(2 * np.pi * i / size) + 0.08 * np.cos(4 * np.pi * i / size) for i in range(size)])
+        Xw = QS.dft(tuple(x.real), 1)                      # floats are accepted, the window applies in rotated order
+        assert np.max(np.abs(np.array(Xw) - np.roll(np.fft.fft(np.roll(x.real, -j0) * w), j0))) < 1e-10
+    assert QS.dft([]) == ()
+    with pytest.raises(QS.error):
+        QS.dft(["a"])
+    resp = QS.get_filter()
+    assert isinstance(resp, tuple) and len(resp) == W and max(resp) > -30.0 and min(resp) < -80.0       # (shaped by the head of the 1024-point display window: quisk.c:4816-4817)
+    tx = QS.get_tx_filter()
+    assert isinstance(tx, tuple) and len(tx) == W
+    assert QS.measure_audio(1) == 0.0 and QS.measure_frequency(0) == 0.0 and QS.measure_frequency(-1) == 0.0
+    assert QS.get_audio_graph() is None
+    QS.set_tune(4000, 0)
+    QS.add_tone(5000)
+    blk = np.zeros(4800, complex)
+    for _ in range(12):
+        QS.add_rx_samples(_raw32(blk)); QS.read_sound()
+    rows = QS.get_graph(1, 1.0, 0.0)
+    k = int(np.argmax(rows))
+    assert abs(k - (W // 2 + 5000 * W // fs)) <= 1          # the tone is where it was put, at -40 dBFS
+    assert abs(max(rows) - (-40.0)) < 3.0
+    assert QS.measure_audio(-1) > 0.0                        # the USB receiver 1 kHz below the tone hears it
+    QS.add_tone(0)
+    QS.close_sound()
