@@ -28,7 +28,7 @@ $(CSRC)/qk_engine.o: $(CSRC)/qk_engine.hip $(CSRC)/qk_kernels.h $(CSRC)/qk_fft.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $(CSRC)/qk_engine.hip
 
 $(LIB): $(CSRC)/qk_engine.o $(CSRC)/qk_phasor.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(CSRC)/qk_engine.o $(CSRC)/qk_phasor.o -lm
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(CSRC)/qk_engine.o $(CSRC)/qk_phasor.o -lm -ldl
 
 oracle:
 	$(MAKE) -C oracle

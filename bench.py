@@ -402,7 +402,7 @@ def main():
 
     from quisk_amd.engine import KT_FRONTEND
     from quisk_amd.synth import make_iq, tune_offsets, mode_mix
-    from quisk_amd.shard import receiver_slice, gather_audio, max_over_ranks
+    from quisk_amd.shard import receiver_slice, max_over_ranks
 
     fs, nrx, block = a.rate, a.receivers, a.block
     total_rx = nrx * world
@@ -411,6 +411,8 @@ def main():
     lo, hi = receiver_slice(total_rx, world, rank)
     tunes, modes = all_tunes[lo:hi], all_modes[lo:hi]
     eng = make_engine(fs, nrx, block, local, tunes, modes, fp32=a.fp32)
+    if world > 1:
+        init_comm(eng)
 
     # synthetic stream resident in HBM: NB distinct blocks (the base block rotated by a different phase each),
     # 256 MiB in total so that successive steps do not re-read a cache-resident input
@@ -427,20 +429,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def init_comm(e):
+        """the library's own RCCL communicator (qk_comm_init): rank 0 makes the id, the launcher's process group only carries it"""
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(e.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        e.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+
     def gather_outputs(e, n_local):
-        """RCCL gather of the last block's audio of every receiver to rank 0 (the only collective of the path)."""
-        counts = torch.tensor([e.L.qk_audio_count(e.h, r) for r in range(n_local)], dtype=torch.int64, device="cuda")
-        stride = int(counts.max().item())
-        send = torch.empty((n_local, stride, 2), dtype=torch.float64, device="cuda")
-        e.export_audio_device(send.data_ptr(), stride)
+        """The only collective of the path: the last block's audio of every receiver to rank 0, over RCCL from inside libqkengine
+        (qk_gather_audio: ncclSend / ncclRecv in one group, straight out of the engine's audio rows)."""
+        _, stride = e.audio_device()
+        dst = torch.empty((world, n_local, stride, 2), dtype=torch.float64, device="cuda") if rank == 0 else None
+        cnt = torch.zeros((world, n_local), dtype=torch.int32, device="cuda") if rank == 0 else None
         barrier()
         g0 = time.perf_counter()
-        audio, cnt = gather_audio(send, counts, dst=0)
+        e.gather_audio(0, dst.data_ptr() if rank == 0 else 0, cnt.data_ptr() if rank == 0 else 0)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - g0) * 1e3
         if rank == 0:
-            assert audio.shape[0] == n_local * world and int(cnt.min().item()) > 0
-        return {"ms": ms, "bytes": int(n_local * world * stride * 16), "receivers": n_local * world}
+            assert int(cnt.min().item()) > 0 and bool(torch.isfinite(dst[:, :, :int(cnt.min().item())]).all().item())
+        return {"ms": ms, "bytes": int(n_local * world * stride * 16), "receivers": n_local * world, "backend": "rccl-c"}
 
     # The headline leg runs twice: once straight after set-up, when the GPU has been idle (its clocks take some 20 ms of
     # load to come up: a 20-step timed region lies wholly inside that ramp), and again -- the figure reported as `value` --
@@ -468,6 +478,7 @@ def main():
                "receivers_total": nrx4 * world, "realtime_factor": v4 * 1e6 / world / fs4,
                "roofline": frontend_roofline(st4, fs4, block, nrx4, dt4 / k4 * 1e3, a.fp32, "r03_pmc_frontend_c4.json", "r03_kernel_stats_default_bench.csv")}
         if world > 1:
+            init_comm(eng4)
             leg["gather"] = gather_outputs(eng4, nrx4)
         later.append(eng4)       # (closed behind the headline leg: freeing its buffers would idle the GPU in front of it)
         res["config4_slice"] = leg

@@ -281,7 +281,8 @@ int quisk_ccfFilter(double *samples, int count, const double *cpx_coefs, int nta
 
 /* The remaining filter.c kernels as host-buffer drop-ins with explicit state (`hist` = the last ntaps - 1 input samples):
  *   qk_cInterpolate   quisk_cInterpolate (filter.c:108-142): complex samples, real taps, x interp in place (the buffer holds
- *                     count * interp complex samples); returns the output count
+ *                     count * interp complex samples); returns the output count, which like the reference's stops at
+ *                     SAMP_BUFFER_SIZE * 8 / 10 = 52800 (filter.c:135)
  *   qk_dC_out_block   quisk_dC_out (filter.c:60-81) over a block: real samples through complex taps (as quisk_filt_tune makes
  *                     them, filter.c:35-58), one complex output per input sample
  *   qk_dD_out_block   quisk_dD_out (filter.c:303-322) over a block: real samples, real taps, in place
@@ -299,6 +300,23 @@ int qk_dD_out_block(double *samples, int count, const double *coefs, int ntaps, 
  * 3496-3499); sockets, sequence numbers and the transmit side stay with the caller.  Returns the number of samples processed. */
 int qk_process_hermes(qk_engine *e, const void *packets, int n_packets, int multirx_count, double *sub_out_host, int *read_errors, int *overrange);
 
+/* Multi-GPU (no counterpart in the reference, which is one process on one CPU; BASELINE.json north_star):
+ * one process and one engine per GPU, the receivers sharded over the ranks, every rank fed the same I/Q stream; the only
+ * exchange is the gather of the outputs to one rank, over RCCL (xGMI) from inside this library: ncclSend / ncclRecv in one
+ * group, on the engine's own stream, straight out of the audio rows.  librccl is loaded on first use.
+ *   qk_comm_unique_id  rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means
+ *   qk_comm_init       every rank: ncclCommInitRank on the engine's device
+ *   qk_gather_audio    the last block's audio of every rank's receivers to dst_rank: dst_dev (device memory on dst_rank,
+ *                      ignored elsewhere) receives [world][n_receivers][stride] complex samples, stride as qk_audio_device
+ *                      reports it, counts_dev [world][n_receivers] the sample counts.  Every rank has the same n_receivers.
+ *   qk_gather_graph    the last released graph row (data_width doubles) of every rank to dst_rank: [world][data_width] */
+#define QK_COMM_ID_BYTES 128
+int qk_comm_unique_id(void *id_out);
+int qk_comm_init(qk_engine *e, const void *id, int rank, int world);
+int qk_comm_destroy(qk_engine *e);
+int qk_gather_audio(qk_engine *e, int dst_rank, double *dst_dev, int *counts_dev);
+int qk_gather_graph(qk_engine *e, int dst_rank, double *dst_dev);
+
 /* No counterpart in the reference.  For callers that cannot allocate: code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  quisk_cCplxSampleFilter (above) with every buffer already in DEVICE memory:
  * samples (count complex, filtered in place), coefs (ntaps doubles), hist (ntaps - 1 complex, updated); *phase is a
@@ -307,7 +325,10 @@ int qk_process_hermes(qk_engine *e, const void *packets, int n_packets, int mult
  * (ntaps - 1 + count) + outputs exceeds it returns QK_ERANGE.  Calls no hipMalloc / hipFree or any allocating routine;
  * the three kernels are queued on `hip_stream` (a hipStream_t; NULL = the default stream) and nothing waits for them.
  * Every call on one GPU shares that GPU's staging array: calls that overlap in time on one GPU race; calls on one
- * stream do not.  Returns the output count, like the reference's functions. */
+ * stream do not.  The array is the one of the stream's device, which must be the current device (QK_EINVAL otherwise).  The
+ * FIRST call on a device looks the array's address up (hipGetSymbolAddress loads the code object and materialises the
+ * array): make one warm-up call per device -- count = 0 will do -- outside any graph capture, with that device current.
+ * Returns the output count, like the reference's functions. */
 #define QK_NOALLOC_MAX_SAMPLES (1 << 19)
 int quisk_cCplxSampleFilter_noalloc(double *samples_dev, int count, const double *coefs_dev, int ntaps, int decim,
                                     double *hist_dev, int *phase, void *hip_stream);

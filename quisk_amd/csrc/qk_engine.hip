@@ -4,6 +4,8 @@
 // include/qk_engine.h.  No CPU fallback: every entry point that computes needs a HIP device.
 #include "../../include/qk_engine.h"
 #include <hip/hip_ext.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 #include "qk_kernels.h"
 #include "qk_fft.h"
 #include <algorithm>
@@ -22,6 +24,21 @@ extern "C" void qk_phase_tables(double pre, double pim, double *C, double *B, do
 #define QK_COEF_TABLE(name, n) static const double name[n]
 #include "qk_coefs.inc"
 
+// librccl is loaded on first use: a one-GPU user of the library does not need it present.
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+} g_rccl;
+std::mutex g_rccl_mu;
+}
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // Flags of the events that order one stream behind another
@@ -267,6 +284,8 @@ struct qk_engine {
     double2 *d_raw_rows = nullptr;
     // cRxFilterOut for callers outside the chain (qk_rx_filter_block): per bank [hist tap_cap][max_block] and an output block
     double2 *d_rfb_x[3] = {nullptr, nullptr, nullptr}, *d_rfb_y = nullptr, *d_rfb_t = nullptr;
+    // RCCL communicator for the output gather (qk_comm_init): one rank per GPU, receivers sharded over the ranks
+    ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1; int *d_counts = nullptr;
     // stats / timing
     qk_stats stats{};
     unsigned timing = 0;       // bit b: time kernel group b (QK_KT_*); bit 8: the whole block
@@ -2316,6 +2335,8 @@ void qk_destroy(qk_engine *e)
     if (e->h_keyup) hipHostFree(e->h_keyup);
     if (e->h_keyup_counts) hipHostFree(e->h_keyup_counts);
     if (e->ev_keyup) hipEventDestroy(e->ev_keyup);
+    if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+    if (e->d_counts) hipFree(e->d_counts);
     for (auto &r : e->routes) { free_chain(r.tail); if (r.d_agc2_ring) hipFree(r.d_agc2_ring); }
     if (e->d_agc_cls) hipFree(e->d_agc_cls);
     if (e->d_zero2) hipFree(e->d_zero2);
@@ -2570,8 +2591,10 @@ int qk_process_samples_int(qk_engine *e, const void *raw, size_t n_bytes, int by
     SYNC_ALL(e);
     if (n_bytes > e->raw_cap) {
         if (e->d_raw) hipFree(e->d_raw);
-        e->raw_cap = (size_t)e->cfg.max_block * 8;
-        HIPCHECK(hipMalloc(&e->d_raw, e->raw_cap));
+        e->d_raw = nullptr; e->raw_cap = 0;
+        const size_t want = (size_t)e->cfg.max_block * 8;
+        HIPCHECK(hipMalloc(&e->d_raw, want));
+        e->raw_cap = want;                           // (only behind a successful allocation: a later call must not trust it otherwise)
     }
     HIPCHECK(hipMemcpyAsync(e->d_raw, raw, n_bytes, hipMemcpyHostToDevice, e->fe_stream));
     hipLaunchKernelGGL(k_unpack_int, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->fe_stream, e->d_raw, e->d_in, (int)n,
@@ -3351,35 +3374,75 @@ int qk_debug_tap(qk_engine *e, int which, int rx, double *out, int cap)
     return m;
 }
 
+// ---- filter.c drop-ins over host buffers ----
+// A grow-only workspace per device, shared by every drop-in call (they take its lock): device input / output buffers and two
+// pinned staging buffers, so that a call costs one host-to-device copy (history, block and taps together), its kernel and one
+// device-to-host copy -- no allocation, no pageable-memory copies.  Held until the process ends.
+namespace {
+struct DropWS { unsigned char *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr; size_t c_in = 0, c_out = 0; hipStream_t st = nullptr; };
+std::mutex g_ws_mu;
+DropWS g_ws[64];
+}
+static int ws_get(DropWS **out, size_t need_in, size_t need_out)
+{
+    int ndev = 0, dev = -1;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(QK_EHIP, "no HIP device: the engine has no CPU path");
+    HIPCHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(QK_ERANGE, "device ordinal beyond the workspace table");
+    DropWS &w = g_ws[dev];
+    if (!w.st) HIPCHECK(hipStreamCreateWithFlags(&w.st, hipStreamNonBlocking));
+    auto grow = [&](unsigned char *&d, unsigned char *&h, size_t &cap, size_t need) -> int {
+        if (need <= cap) return QK_OK;
+        if (d) hipFree(d);
+        if (h) hipHostFree(h);
+        d = nullptr; h = nullptr; cap = 0;
+        const size_t want = need + need / 2 + 4096;
+        HIPCHECK(hipMalloc(&d, want));
+        HIPCHECK(hipHostMalloc(&h, want, hipHostMallocDefault));
+        cap = want;
+        return QK_OK;
+    };
+    int rc = grow(w.d_in, w.h_in, w.c_in, need_in);
+    if (rc == QK_OK) rc = grow(w.d_out, w.h_out, w.c_out, need_out);
+    if (rc != QK_OK) return rc;
+    *out = &w;
+    return QK_OK;
+}
+// the decimating FIR over the staged block: the tiled kernel where its tile fits 48 KiB of LDS, else the plain one
+static void launch_cfir(hipStream_t st, const double2 *x, double2 *y, const double *h, int T, int D, int first, int n_out, int cpx)
+{
+    const size_t lds2 = 16 * ((size_t)D * 511 + T), lds1 = 16 * ((size_t)D * 255 + T);
+    if (lds2 <= 48 * 1024) hipLaunchKernelGGL(k_cfir_lds<2>, dim3((n_out + 511) / 512), dim3(256), lds2, st, x, y, h, T, D, first, n_out, cpx);
+    else if (lds1 <= 48 * 1024) hipLaunchKernelGGL(k_cfir_lds<1>, dim3((n_out + 255) / 256), dim3(256), lds1, st, x, y, h, T, D, first, n_out, cpx);
+    else hipLaunchKernelGGL(k_cfir_interleaved, dim3((n_out + 255) / 256), dim3(256), 0, st, x, y, h, T, D, first, n_out, cpx);
+}
+
 static int fir_dropin(double *samples, int count, const double *coefs, int ntaps, int decim, double *hist, int *phase, int cpx)
 {
     if (!samples || !coefs || !hist || !phase || count < 0 || ntaps < 1 || decim < 1 || *phase < 0 || *phase >= decim)
         return fail(QK_EINVAL, "bad FIR arguments");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(QK_EHIP, "no HIP device: the engine has no CPU path");
     const int n_out = (*phase + count) / decim, first = decim - 1 - *phase;
-    const size_t nh = (size_t)ntaps - 1, ntot = nh + (size_t)count;
-    double2 *dx = nullptr, *dy = nullptr; double *dh = nullptr;
-    auto cleanup = [&]() { if (dx) hipFree(dx); if (dy) hipFree(dy); if (dh) hipFree(dh); };
-#define DROPCHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(QK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
-    DROPCHECK(hipMalloc(&dx, std::max<size_t>(ntot, 1) * sizeof(double2)));
-    DROPCHECK(hipMalloc(&dy, std::max<size_t>(n_out, 1) * sizeof(double2)));
-    DROPCHECK(hipMalloc(&dh, (size_t)ntaps * (cpx ? 2 : 1) * sizeof(double)));
-    if (nh) DROPCHECK(hipMemcpy(dx, hist, nh * sizeof(double2), hipMemcpyHostToDevice));
-    if (count) DROPCHECK(hipMemcpy(dx + nh, samples, (size_t)count * sizeof(double2), hipMemcpyHostToDevice));
-    DROPCHECK(hipMemcpy(dh, coefs, (size_t)ntaps * (cpx ? 2 : 1) * sizeof(double), hipMemcpyHostToDevice));
+    const size_t nh = (size_t)ntaps - 1, ntot = nh + (size_t)count, ncoef = (size_t)ntaps * (cpx ? 2 : 1);
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    DropWS *w = nullptr;
+    int rc = ws_get(&w, ntot * sizeof(double2) + ncoef * sizeof(double), std::max<size_t>(n_out, 1) * sizeof(double2));
+    if (rc != QK_OK) return rc;
+    // history, block and taps go over in one copy
+    if (nh) memcpy(w->h_in, hist, nh * sizeof(double2));
+    if (count) memcpy(w->h_in + nh * sizeof(double2), samples, (size_t)count * sizeof(double2));
+    memcpy(w->h_in + ntot * sizeof(double2), coefs, ncoef * sizeof(double));
+    HIPCHECK(hipMemcpyAsync(w->d_in, w->h_in, ntot * sizeof(double2) + ncoef * sizeof(double), hipMemcpyHostToDevice, w->st));
     if (n_out > 0) {
-        hipLaunchKernelGGL(k_cfir_interleaved, dim3((n_out + 255) / 256), dim3(256), 0, 0, dx, dy, dh, ntaps, decim, first, n_out, cpx);
-        DROPCHECK(hipGetLastError());
+        launch_cfir(w->st, reinterpret_cast<const double2 *>(w->d_in), reinterpret_cast<double2 *>(w->d_out),
+                    reinterpret_cast<const double *>(w->d_in + ntot * sizeof(double2)), ntaps, decim, first, n_out, cpx);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(w->h_out, w->d_out, (size_t)n_out * sizeof(double2), hipMemcpyDeviceToHost, w->st));
     }
-    // new history = the last ntaps-1 samples of (old history + block); read before the outputs overwrite `samples`
-    std::vector<double> nhist(2 * nh);
-    if (nh) DROPCHECK(hipMemcpy(nhist.data(), dx + (ntot - nh), nh * sizeof(double2), hipMemcpyDeviceToHost));
-    if (n_out > 0) DROPCHECK(hipMemcpy(samples, dy, (size_t)n_out * sizeof(double2), hipMemcpyDeviceToHost));
-#undef DROPCHECK
-    if (nh) memcpy(hist, nhist.data(), nh * sizeof(double2));
+    HIPCHECK(hipStreamSynchronize(w->st));
+    // new history = the last ntaps-1 samples of (old history + block): the host has them already
+    if (nh) memcpy(hist, w->h_in + (ntot - nh) * sizeof(double2), nh * sizeof(double2));
+    if (n_out > 0) memcpy(samples, w->h_out, (size_t)n_out * sizeof(double2));
     *phase = (*phase + count) % decim;
-    cleanup();
     return n_out;
 }
 
@@ -3387,37 +3450,37 @@ static int fir_dropin(double *samples, int count, const double *coefs, int ntaps
 static int hist_dropin(const void *in, size_t in_elem, int count, const double *coefs, size_t coef_doubles, int ntaps, void *hist,
                        void *out, size_t out_elem, size_t n_out, int kind, int L)
 {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(QK_EHIP, "no HIP device: the engine has no CPU path");
     const size_t nh = (size_t)ntaps - 1, ntot = nh + (size_t)count;
-    unsigned char *dx = nullptr, *dy = nullptr; double *dh = nullptr;
-    auto cleanup = [&]() { if (dx) hipFree(dx); if (dy) hipFree(dy); if (dh) hipFree(dh); };
-#define DROPCHECK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return fail(QK_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } } while (0)
-    DROPCHECK(hipMalloc(&dx, std::max<size_t>(ntot, 1) * in_elem));
-    DROPCHECK(hipMalloc(&dy, std::max<size_t>(n_out, 1) * out_elem));
-    DROPCHECK(hipMalloc(&dh, coef_doubles * sizeof(double)));
-    if (nh) DROPCHECK(hipMemcpy(dx, hist, nh * in_elem, hipMemcpyHostToDevice));
-    if (count) DROPCHECK(hipMemcpy(dx + nh * in_elem, in, (size_t)count * in_elem, hipMemcpyHostToDevice));
-    DROPCHECK(hipMemcpy(dh, coefs, coef_doubles * sizeof(double), hipMemcpyHostToDevice));
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    DropWS *w = nullptr;
+    const size_t in_bytes = (ntot * in_elem + 15) / 16 * 16;
+    int rc = ws_get(&w, in_bytes + coef_doubles * sizeof(double), std::max<size_t>(n_out, 1) * out_elem);
+    if (rc != QK_OK) return rc;
+    if (nh) memcpy(w->h_in, hist, nh * in_elem);
+    if (count) memcpy(w->h_in + nh * in_elem, in, (size_t)count * in_elem);
+    memcpy(w->h_in + in_bytes, coefs, coef_doubles * sizeof(double));
+    HIPCHECK(hipMemcpyAsync(w->d_in, w->h_in, in_bytes + coef_doubles * sizeof(double), hipMemcpyHostToDevice, w->st));
     if (n_out > 0) {
         const dim3 grid((unsigned)((n_out + 255) / 256));
-        if (kind == 0) hipLaunchKernelGGL(k_cinterp_interleaved, grid, dim3(256), 0, 0, (const double2 *)dx, (double2 *)dy, dh, ntaps, L, count);
-        else hipLaunchKernelGGL(k_dfir_out, grid, dim3(256), 0, 0, (const double *)dx, (double *)dy, dh, ntaps, count, kind == 2);
-        DROPCHECK(hipGetLastError());
+        const double *dh = reinterpret_cast<const double *>(w->d_in + in_bytes);
+        if (kind == 0) hipLaunchKernelGGL(k_cinterp_interleaved, grid, dim3(256), 0, w->st, (const double2 *)w->d_in, (double2 *)w->d_out, dh, ntaps, L, count);
+        else hipLaunchKernelGGL(k_dfir_out, grid, dim3(256), 0, w->st, (const double *)w->d_in, (double *)w->d_out, dh, ntaps, count, kind == 2);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(w->h_out, w->d_out, n_out * out_elem, hipMemcpyDeviceToHost, w->st));
     }
-    std::vector<unsigned char> nhist(nh * in_elem);
-    if (nh) DROPCHECK(hipMemcpy(nhist.data(), dx + (ntot - nh) * in_elem, nh * in_elem, hipMemcpyDeviceToHost));
-    if (n_out > 0) DROPCHECK(hipMemcpy(out, dy, n_out * out_elem, hipMemcpyDeviceToHost));
-#undef DROPCHECK
-    if (nh) memcpy(hist, nhist.data(), nh * in_elem);
-    cleanup();
+    HIPCHECK(hipStreamSynchronize(w->st));
+    if (nh) memcpy(hist, w->h_in + (ntot - nh) * in_elem, nh * in_elem);
+    if (n_out > 0) memcpy(out, w->h_out, n_out * out_elem);
     return (int)n_out;
 }
 
 int qk_cInterpolate(double *samples, int count, const double *coefs, int ntaps, int interp, double *hist)
 {
     if (!samples || !coefs || !hist || count < 0 || ntaps < 1 || interp < 1) return fail(QK_EINVAL, "bad interpolator arguments");      // (nTaps / interp terms per phase: a remainder is left out, filter.c:130)
-    return hist_dropin(samples, sizeof(double2), count, coefs, (size_t)ntaps, ntaps, hist, samples, sizeof(double2), (size_t)count * interp, 0, interp);
+    // the reference stops writing at SAMP_BUFFER_SIZE * 8 / 10 outputs (filter.c:135): a caller's buffer sized like the reference's is
+    // never overrun; the history still takes in every input sample
+    const size_t n_out = std::min((size_t)count * interp, (size_t)66000 * 8 / 10);
+    return hist_dropin(samples, sizeof(double2), count, coefs, (size_t)ntaps, ntaps, hist, samples, sizeof(double2), n_out, 0, interp);
 }
 int qk_dC_out_block(const double *samples, int count, const double *cpx_coefs, int ntaps, double *hist, double *out_complex)
 {
@@ -3458,13 +3521,17 @@ int qk_process_hermes(qk_engine *e, const void *packets, int n_packets, int mult
     const size_t bytes = (size_t)n_packets * 1032;
     if (bytes > e->raw_cap) {
         if (e->d_raw) hipFree(e->d_raw);
-        e->d_raw = nullptr;
-        e->raw_cap = std::max(bytes, (size_t)e->cfg.max_block * 8);
-        HIPCHECK(hipMalloc(&e->d_raw, e->raw_cap));
+        e->d_raw = nullptr; e->raw_cap = 0;
+        const size_t want = std::max(bytes, (size_t)e->cfg.max_block * 8);
+        HIPCHECK(hipMalloc(&e->d_raw, want));
+        e->raw_cap = want;
     }
     double2 *d_sub = nullptr;
     if (sub_out_host && multirx_count > 0) HIPCHECK(hipMalloc(&d_sub, sizeof(double2) * (size_t)n * multirx_count));
-    HIPCHECK(hipMemcpyAsync(e->d_raw, packets, bytes, hipMemcpyHostToDevice, e->fe_stream));
+    {
+        hipError_t ce = hipMemcpyAsync(e->d_raw, packets, bytes, hipMemcpyHostToDevice, e->fe_stream);
+        if (ce != hipSuccess) { if (d_sub) hipFree(d_sub); return fail(QK_EHIP, hipGetErrorString(ce)); }
+    }
     hipLaunchKernelGGL(k_unpack_hermes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->fe_stream, e->d_raw, n_packets, nrx, num_records,
                        e->d_in, d_sub, n);
     if (d_sub) {
@@ -3484,10 +3551,14 @@ int qk_process_hermes(qk_engine *e, const void *packets, int n_packets, int mult
 static __device__ __align__(256) double2 qk_na_scratch[QK_NOALLOC_MAX_SAMPLES];
 static std::mutex g_na_mu;
 static double2 *g_na_ptr[64] = {nullptr};
-static int noalloc_scratch(double2 **out)
+static int noalloc_scratch(double2 **out, hipStream_t st)
 {
-    int dev = -1;
-    HIPCHECK(hipGetDevice(&dev));
+    // the array of the device that will run the kernels: the stream's own device; the current one for the NULL stream
+    int dev = -1, cur = -1;
+    HIPCHECK(hipGetDevice(&cur));
+    dev = cur;
+    if (st) HIPCHECK(hipStreamGetDevice(st, &dev));
+    if (dev != cur) return fail(QK_EINVAL, "quisk_cCplxSampleFilter_noalloc: the stream belongs to another device than the current one");
     if (dev < 0 || dev >= 64) return fail(QK_ERANGE, "device ordinal beyond the scratch table");
     std::lock_guard<std::mutex> lk(g_na_mu);
     if (!g_na_ptr[dev]) {
@@ -3511,15 +3582,14 @@ int quisk_cCplxSampleFilter_noalloc(double *samples_dev, int count, const double
         return fail(QK_ERANGE, "quisk_cCplxSampleFilter_noalloc: (ntaps - 1 + count) + outputs exceeds the fixed scratch of "
                                "QK_NOALLOC_MAX_SAMPLES complex samples; split the block");
     double2 *scratch = nullptr;
-    int rc = noalloc_scratch(&scratch);
-    if (rc != QK_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    int rc = noalloc_scratch(&scratch, st);
+    if (rc != QK_OK) return rc;
     double2 *cat = scratch, *y = scratch + ntot;
     if (ntot > 0)
         hipLaunchKernelGGL(k_na_gather, dim3((unsigned)((ntot + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const double2 *>(hist_dev),
                            reinterpret_cast<const double2 *>(samples_dev), cat, (int)nh, count);
-    if (n_out > 0)
-        hipLaunchKernelGGL(k_cfir_interleaved, dim3((n_out + 255) / 256), dim3(256), 0, st, cat, y, coefs_dev, ntaps, decim, first, n_out, 0);
+    if (n_out > 0) launch_cfir(st, cat, y, coefs_dev, ntaps, decim, first, n_out, 0);
     const long long m = std::max<long long>(n_out, nh);
     if (m > 0)
         hipLaunchKernelGGL(k_na_scatter, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, cat, y, reinterpret_cast<double2 *>(samples_dev),
@@ -3527,6 +3597,118 @@ int quisk_cCplxSampleFilter_noalloc(double *samples_dev, int count, const double
     HIPCHECK(hipGetLastError());
     *phase = (*phase + count) % decim;
     return n_out;
+}
+
+// ---- multi-GPU: the gather of the outputs over RCCL (xGMI), from C ----
+static int rccl_load()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return QK_OK;
+    // The copy that belongs to the HIP runtime this library is bound to: a process may hold a second ROCm stack (PyTorch wheels
+    // bundle one, same sonames), and an RCCL of the other stack would bring up an HSA runtime of its own and find no device.
+    // So: the directory of the libamdhip64 that serves our calls first, by path; its own symbols first (RTLD_DEEPBIND).
+    void *h = nullptr;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash + 1);
+            for (const char *nm : {"librccl.so.1", "librccl.so"}) {
+                h = dlopen((dir + nm).c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+                if (h) break;
+            }
+        }
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+    if (!h) return fail(QK_EUNSUPPORTED, std::string("librccl not found: ") + dlerror());
+#define QK_SYM(field, name) do { *(void **)(&g_rccl.field) = dlsym(h, name); if (!g_rccl.field) return fail(QK_EUNSUPPORTED, "librccl lacks " name); } while (0)
+    QK_SYM(GetUniqueId, "ncclGetUniqueId"); QK_SYM(CommInitRank, "ncclCommInitRank"); QK_SYM(CommDestroy, "ncclCommDestroy");
+    QK_SYM(Send, "ncclSend"); QK_SYM(Recv, "ncclRecv"); QK_SYM(GroupStart, "ncclGroupStart"); QK_SYM(GroupEnd, "ncclGroupEnd");
+    QK_SYM(GetErrorString, "ncclGetErrorString");
+#undef QK_SYM
+    g_rccl.lib = h;
+    return QK_OK;
+}
+#define NCCLCHECK(expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) return fail(QK_EHIP, std::string(#expr) + ": " + g_rccl.GetErrorString(_r)); } while (0)
+
+int qk_comm_unique_id(void *id_out)
+{
+    if (!id_out) return fail(QK_EINVAL, "null argument");
+    int rc = rccl_load();
+    if (rc != QK_OK) return rc;
+    ncclUniqueId id;
+    NCCLCHECK(g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return QK_OK;
+}
+
+int qk_comm_init(qk_engine *e, const void *id, int rank, int world)
+{
+    ENGINE_ENTER(e);
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(QK_EINVAL, "bad communicator arguments");
+    if (e->comm) return fail(QK_EINVAL, "the engine already has a communicator");
+    int rc = rccl_load();
+    if (rc != QK_OK) return rc;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    NCCLCHECK(g_rccl.CommInitRank(&e->comm, world, uid, rank));
+    e->comm_rank = rank; e->comm_world = world;
+    if (e->nrx > 0) HIPCHECK(hipMalloc(&e->d_counts, sizeof(int) * e->nrx));
+    return QK_OK;
+}
+
+int qk_comm_destroy(qk_engine *e)
+{
+    ENGINE_ENTER(e);
+    if (e->comm) { SYNC_ALL(e); g_rccl.CommDestroy(e->comm); e->comm = nullptr; }
+    if (e->d_counts) { hipFree(e->d_counts); e->d_counts = nullptr; }
+    return QK_OK;
+}
+
+int qk_gather_audio(qk_engine *e, int dst_rank, double *dst_dev, int *counts_dev)
+{
+    ENGINE_ENTER(e);
+    if (!e->comm) return fail(QK_EINVAL, "no communicator (qk_comm_init)");
+    if (dst_rank < 0 || dst_rank >= e->comm_world || e->nrx <= 0) return fail(QK_EINVAL, "bad gather arguments");
+    const bool root = e->comm_rank == dst_rank;
+    if (root && (!dst_dev || !counts_dev)) return fail(QK_EINVAL, "the destination rank needs its buffers");
+    // the AGC passes write the audio rows; the sends come behind them on the chain's stream
+    HIPCHECK(hipStreamSynchronize(e->agc_stream));
+    if (e->apply_stream) HIPCHECK(hipStreamSynchronize(e->apply_stream));
+    AGC_ABORT_CHECK(e);
+    HIPCHECK(hipMemcpyAsync(e->d_counts, e->out_count.data(), sizeof(int) * e->nrx, hipMemcpyHostToDevice, e->stream));
+    const size_t row = (size_t)e->nrx * e->out_stride * 2;          // doubles per rank
+    NCCLCHECK(g_rccl.GroupStart());
+    NCCLCHECK(g_rccl.Send(e->d_out, row, ncclDouble, dst_rank, e->comm, e->stream));
+    NCCLCHECK(g_rccl.Send(e->d_counts, (size_t)e->nrx, ncclInt, dst_rank, e->comm, e->stream));
+    if (root)
+        for (int r = 0; r < e->comm_world; r++) {
+            NCCLCHECK(g_rccl.Recv(dst_dev + (size_t)r * row, row, ncclDouble, r, e->comm, e->stream));
+            NCCLCHECK(g_rccl.Recv(counts_dev + (size_t)r * e->nrx, (size_t)e->nrx, ncclInt, r, e->comm, e->stream));
+        }
+    NCCLCHECK(g_rccl.GroupEnd());
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return QK_OK;
+}
+
+int qk_gather_graph(qk_engine *e, int dst_rank, double *dst_dev)
+{
+    ENGINE_ENTER(e);
+    if (!e->comm) return fail(QK_EINVAL, "no communicator (qk_comm_init)");
+    if (dst_rank < 0 || dst_rank >= e->comm_world || e->fftN <= 0) return fail(QK_EINVAL, "bad gather arguments");
+    const bool root = e->comm_rank == dst_rank;
+    if (root && !dst_dev) return fail(QK_EINVAL, "the destination rank needs its buffer");
+    const size_t W = (size_t)e->fftW;
+    HIPCHECK(hipStreamSynchronize(e->fe_stream));                    // the release kernel writes the row on the front end's stream
+    NCCLCHECK(g_rccl.GroupStart());
+    NCCLCHECK(g_rccl.Send(e->d_graph, W, ncclDouble, dst_rank, e->comm, e->stream));
+    if (root)
+        for (int r = 0; r < e->comm_world; r++) NCCLCHECK(g_rccl.Recv(dst_dev + (size_t)r * W, W, ncclDouble, r, e->comm, e->stream));
+    NCCLCHECK(g_rccl.GroupEnd());
+    HIPCHECK(hipStreamSynchronize(e->stream));
+    return QK_OK;
 }
 
 long long qk_debug_agc_passes(qk_engine *e, int rx)

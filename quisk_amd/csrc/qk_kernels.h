@@ -1846,6 +1846,59 @@ __global__ __launch_bounds__(256) void k_cfir_interleaved(const double2 *x, doub
     y[j] = make_double2(ar, ai);
 }
 
+// The same, LDS-tiled: a workgroup makes 256 R consecutive outputs from the D (256 R - 1) + T input samples they need, staged
+// once in LDS as a real and an imaginary plane (so an input sample is fetched from memory once instead of T / D times); lane
+// l makes outputs l, l + 256, ...: neighbouring lanes read LDS words D apart.  The taps are wave-uniform scalar loads shared by
+// the lane's R outputs.  Every output's sum runs over k = 0 .. T-1 in the reference's order, with the operations of
+// k_cfir_interleaved: the two kernels give identical bits.  Dynamic LDS: 16 (D (256 R - 1) + T) bytes.
+template <int R>
+__global__ __launch_bounds__(256) void k_cfir_lds(const double2 *__restrict__ x, double2 *__restrict__ y, const double *__restrict__ h, int T, int D,
+                                                  int first, int n_out, int cpx)
+{
+    extern __shared__ __attribute__((aligned(16))) double cf_lds[];
+    const int S = D * (256 * R - 1) + T;
+    double *re = cf_lds, *im = cf_lds + S;
+    const int j0 = blockIdx.x * (256 * R);
+    const long long base = first + (long long)D * j0;                       // x index of the oldest sample of the tile
+    const long long last = (long long)(T - 1) + first + (long long)D * (n_out - 1);   // newest sample any output needs
+    for (int i = threadIdx.x; i < S; i += 256) {
+        const long long idx = base + i;
+        const double2 v = x[idx < last ? idx : last];
+        re[i] = v.x; im[i] = v.y;
+    }
+    __syncthreads();
+    double ar[R], ai[R];
+    int nw[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { ar[r] = 0.0; ai[r] = 0.0; nw[r] = D * ((int)threadIdx.x + 256 * r) + T - 1; }
+    if (cpx) {
+        const double2 *c = reinterpret_cast<const double2 *>(h);
+        for (int k = 0; k < T; k++) {
+            const double2 w = c[k];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const double vx = re[nw[r] - k], vy = im[nw[r] - k];
+                ar[r] += vx * w.x - vy * w.y;
+                ai[r] += vx * w.y + vy * w.x;
+            }
+        }
+    } else {
+        for (int k = 0; k < T; k++) {
+            const double hk = h[k];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                ar[r] = fma(re[nw[r] - k], hk, ar[r]);
+                ai[r] = fma(im[nw[r] - k], hk, ai[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int j = j0 + (int)threadIdx.x + 256 * r;
+        if (j < n_out) y[j] = make_double2(ar[r], ai[r]);
+    }
+}
+
 // The allocation-free drop-in (quisk_cCplxSampleFilter_noalloc): the filter runs in place, so inputs are staged.  Scratch
 // layout: cat[nh + count] = history followed by the block (what k_cfir_interleaved reads), then y[n_out].
 __global__ __launch_bounds__(256) void k_na_gather(const double2 *hist, const double2 *samples, double2 *cat, int nh, int count)

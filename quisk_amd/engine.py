@@ -102,6 +102,11 @@ def lib():
     L.qk_dD_out_block.argtypes = [vp, C.c_int, vp, C.c_int, vp]
     L.qk_process_hermes.argtypes = [vp, vp, C.c_int, C.c_int, vp, ip, ip]
     L.quisk_cCplxSampleFilter_noalloc.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, ip, vp]
+    L.qk_comm_unique_id.argtypes = [vp]
+    L.qk_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.qk_comm_destroy.argtypes = [vp]
+    L.qk_gather_audio.argtypes = [vp, C.c_int, vp, vp]
+    L.qk_gather_graph.argtypes = [vp, C.c_int, vp]
     L.qk_add_tone.argtypes = [vp, C.c_int]
     L.qk_get_filter.argtypes = [vp, vp, C.c_int]
     L.qk_measure_audio.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
@@ -221,6 +226,27 @@ class Engine:
     def route_tap(self, rx):
         """(debug) the pair of receiver rx's live stereo route in front of its two AGCs: [2][count], left and right"""
         return self.tap(TAP_ROUTE, rx, planes=2, cap=self.out_cap + 32768)
+
+    # ---- multi-GPU: the output gather over RCCL, inside the library (include/qk_engine.h) ----
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes made by rank 0 (ncclGetUniqueId), to be handed to every rank"""
+        buf = C.create_string_buffer(128)
+        _check(lib().qk_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid, rank, world):
+        _check(self.L.qk_comm_init(self.h, C.c_char_p(bytes(uid)), int(rank), int(world)))
+
+    def comm_destroy(self):
+        _check(self.L.qk_comm_destroy(self.h))
+
+    def gather_audio(self, dst_rank, dst_dev_ptr, counts_dev_ptr):
+        """every rank's last audio block to dst_rank: [world][n_receivers][stride] complex + [world][n_receivers] counts (device)"""
+        _check(self.L.qk_gather_audio(self.h, int(dst_rank), C.c_void_p(dst_dev_ptr), C.c_void_p(counts_dev_ptr)))
+
+    def gather_graph(self, dst_rank, dst_dev_ptr):
+        _check(self.L.qk_gather_graph(self.h, int(dst_rank), C.c_void_p(dst_dev_ptr)))
 
     def add_tone(self, freq_hz):
         """add_tone (quisk.c:3022-3034): the test tone of AddTestTone at freq_hz from the centre; 0 = off."""

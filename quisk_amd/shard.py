@@ -1,6 +1,8 @@
 """Multi-GPU sharding of the receive path: one process per GPU, receivers partitioned across ranks, every rank
 reads the same I/Q stream.  The path has no exchange step; the only collective is the gather of the outputs
-(audio blocks, graph row) to one rank, over RCCL (backend "nccl") on GPUs or gloo on CPUs (tests)."""
+(audio blocks, graph row) to one rank.  On GPUs that gather lives inside libqkengine (qk_comm_init / qk_gather_audio /
+qk_gather_graph: RCCL from C, include/qk_engine.h); this module keeps the partition arithmetic, the harness's max-over-ranks
+and a torch.distributed form of the same gather layout that the CPU tests run under gloo (tests/test_shard_gloo.py)."""
 import torch
 import torch.distributed as dist
 

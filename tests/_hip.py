@@ -62,6 +62,20 @@ class DevBuf:
             pass
 
 
+def stream_create():
+    L = rt()
+    L.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    st = C.c_void_p()
+    _ok(L.hipStreamCreate(C.byref(st)), "hipStreamCreate")
+    return st
+
+
+def stream_destroy(st):
+    L = rt()
+    L.hipStreamDestroy.argtypes = [C.c_void_p]
+    _ok(L.hipStreamDestroy(st), "hipStreamDestroy")
+
+
 def sync():
     _ok(rt().hipDeviceSynchronize(), "hipDeviceSynchronize")
 

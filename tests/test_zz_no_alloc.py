@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from _hip import DevBuf, free_bytes, sync
+from _hip import DevBuf, free_bytes, stream_create, stream_destroy, sync
 from quisk_amd import lib
 
 pytestmark = pytest.mark.gpu
@@ -70,3 +70,31 @@ def test_noalloc_entry_point_refuses_oversized_blocks():
                                            C.c_void_p(d_hist.ptr), C.byref(phase), None)
     assert rc == -4 and b"scratch" in L.qk_last_error()          # QK_ERANGE
     assert phase.value == 0
+
+
+def test_noalloc_on_a_created_stream_and_the_priming_call():
+    """count = 0 is the warm-up call the header asks for (it looks the staging array up and leaves everything alone, the history
+    included); then a call on a stream of the caller's own, against the allocating entry point."""
+    L = lib()
+    ntaps, decim, n = 147, 3, 30001
+    rng = np.random.default_rng(5)
+    h = rng.standard_normal(ntaps)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 2.0 ** 18
+    hist0 = (rng.standard_normal(ntaps - 1) + 1j * rng.standard_normal(ntaps - 1)) * 2.0 ** 18
+    hist_h = hist0.copy()
+    want, phase_h = _host_call(L, x, h, decim, hist_h, 1)
+    d_h, d_hist, d_x = DevBuf(h), DevBuf(hist0), DevBuf(x)
+    phase = C.c_int(1)
+    m0 = L.quisk_cCplxSampleFilter_noalloc(C.c_void_p(d_x.ptr), 0, C.c_void_p(d_h.ptr), ntaps, decim, C.c_void_p(d_hist.ptr), C.byref(phase), None)
+    sync()
+    assert m0 == 0 and phase.value == 1
+    assert np.array_equal(d_hist.to_host(np.complex128), hist0)                 # nothing in, nothing moved
+    st = stream_create()
+    free_before = free_bytes()
+    m = L.quisk_cCplxSampleFilter_noalloc(C.c_void_p(d_x.ptr), n, C.c_void_p(d_h.ptr), ntaps, decim, C.c_void_p(d_hist.ptr), C.byref(phase), st)
+    sync()
+    assert free_bytes() == free_before
+    assert m == len(want) and phase.value == phase_h
+    assert np.array_equal(d_x.to_host(np.complex128)[:m].view(np.float64), want.view(np.float64))
+    assert np.array_equal(d_hist.to_host(np.complex128), hist_h)
+    stream_destroy(st)
