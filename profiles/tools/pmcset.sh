@@ -7,7 +7,7 @@
 tag=$1
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-spectrum --no-config4 --no-config5 --no-config1 --steps 3 --warmup 1"
+B="python $R/bench.py --no-cpu-baseline --no-spectrum --no-config4 --no-config5 --no-config1 --no-one-gpu --steps 3 --warmup 1"
 run() { # name counters... -- command
   name=$1; shift; ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
   timeout -s KILL 150 rocprofv3 --pmc "${ctr[@]}" --output-format csv -d $R/gpurun_out/${tag}_${name} -- "$@" > $R/gpurun_out/${tag}_${name}.log 2>&1 || { echo "pass $name failed"; tail -5 $R/gpurun_out/${tag}_${name}.log; exit 1; }

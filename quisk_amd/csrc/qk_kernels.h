@@ -164,7 +164,13 @@ struct FwLayout {
     static __host__ __device__ constexpr int sub(int s) { return (FW_CHUNK >> (s + 1)) + FE_HIST + (s == 2 ? 16 : s == 4 ? 18 : 14); }   // (pads chosen so that a stage's stores into the next level's E and O arrays fall on disjoint banks)
     static __host__ __device__ constexpr int level_off(int s) { int o = 0; for (int i = 0; i < s; i++) o += 4 * sub(i); return o; }
     static __host__ __device__ constexpr int total(int S) { return level_off(S) + 16; }
-    static __host__ __device__ constexpr int R(int s) { return s == 0 ? 6 : s == 1 ? 3 : s == 2 ? 2 : 1; }
+#ifndef FE_EVEN_R
+#define FE_EVEN_R 0
+#endif
+    // outputs per lane at level s.  (FE_EVEN_R, double only: even counts everywhere, so that every window starts on a 16-byte
+    // boundary and is read with compiler-visible ds_read_b128 -- no spelled-out reads, the compiler counts the waits itself)
+    static __host__ __device__ constexpr int R(int s, int esz = 8)
+    { return (FE_EVEN_R && esz == 8) ? (s == 0 ? 6 : s == 1 ? 4 : 2) : (s == 0 ? 6 : s == 1 ? 3 : s == 2 ? 2 : 1); }
     static __host__ __device__ constexpr int warm(int S) { return ((44 << S) + 63) / 64 * 64; }
 };
 template <class T>
@@ -180,7 +186,7 @@ __device__ __forceinline__ void hb45_out(const T *__restrict__ O, const T *__res
     typedef typename QkVec2<T>::type V2;
     T o[R + 22];
     T e[R + 1];
-    if constexpr (sizeof(T) == 8 && R == 2 && LAST) {
+    if constexpr (sizeof(T) == 8 && R == 2 && LAST && !FE_EVEN_R) {
         // (23 + 2 single reads: measured faster than the 13 ds_read_b128 of the vector form where this is the last level and
         // all 64 lanes read -- 398 against 405 us at S = 3 -- and slower where it is not: 248 against 233 us at S = 4)
         const unsigned ao = (unsigned)reinterpret_cast<size_t>(O + m0 + 2), ae = (unsigned)reinterpret_cast<size_t>(E + m0 + 12);
@@ -329,9 +335,9 @@ __device__ __forceinline__ void fw_carry_store(T *smem, int s, int lane, const T
 
 template <class T, int S, int s>
 __device__ __forceinline__ void fw_stage(T *smem, int c, int lane, bool emit, double *out0, double *out1, long long obase, long long dummy,
-                                         T (&pend_y)[FwLayout::R(S - 1)], long long (&pend_i)[FwLayout::R(S - 1)])
+                                         T (&pend_y)[FwLayout::R(S - 1, sizeof(T))], long long (&pend_i)[FwLayout::R(S - 1, sizeof(T))])
 {
-    constexpr int R = FwLayout::R(s);
+    constexpr int R = FwLayout::R(s, sizeof(T));
     const int n_out = c >> (s + 1);
     const int plane = lane >> 5, q = lane & 31;
     const int m0 = q * R;
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FE_WAVES_PER
 #else
 #define FE_PROBE(k) do { } while (0)
 #endif
-    constexpr int RL = FwLayout::R(S - 1);
+    constexpr int RL = FwLayout::R(S - 1, sizeof(T));
     T pend_y[RL];
     long long pend_i[RL];
 #pragma unroll
