@@ -239,12 +239,14 @@ def frontend_roofline(st, fs, block, nrx, dt_step_ms, fp32, pmc_name, rocprof_cs
     esz = 8 if fp32 else 16
     # the same kernel's average duration in the committed rocprofv3 summary of this command: the HIP-event figure includes the
     # wait of the second event behind other queues' packets, the profiler's is the kernel's own begin-to-end time
-    rp_ms = rocprof_kernel_ms(rocprof_csv, "k_frontend_wave<%d, %s>" % (S, "float" if fp32 else "double")) if rocprof_csv else None
+    needle = ("k_frontend_pk<%d>" % S) if (fp32 and os.environ.get("QK_FE_PACKED", "1") != "0") else "k_frontend_wave<%d, %s>" % (S, "float" if fp32 else "double")
+    rp_ms = rocprof_kernel_ms(rocprof_csv, needle) if rocprof_csv else None
     rp = None
     if rp_ms:
         rp = {"avg_launch_ms": rp_ms, "achieved": fe_flops / (rp_ms * 1e-3) / 1e12, "frac": fe_flops / (rp_ms * 1e-3) / 1e12 / peak,
               "source": "profiles/%s (rocprofv3 --kernel-trace --stats of an earlier run of this command)" % rocprof_csv}
-    return {"kernel": "k_frontend_wave<S=%d> (mixer + %d fused half-band decimators)" % (S, S), "rocprof": rp,
+    return {"kernel": ("k_frontend_pk<S=%d> (packed-FP32 mixer + %d fused half-band decimators)" if needle.startswith("k_frontend_pk") else
+                       "k_frontend_wave<S=%d> (mixer + %d fused half-band decimators)") % (S, S), "rocprof": rp,
             "bound": "valu", "pipe": "fp32 vector FMA" if fp32 else "fp64 vector FMA", "achieved": achieved_tf, "peak": peak,
             "unit": "TFLOP/s", "frac": achieved_tf / peak, "traffic": traffic, "traffic_source": source,
             "avg_launch_ms": fe_ms, "launches": int(st.kernel_launches[KT_FRONTEND]),

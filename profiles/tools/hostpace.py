@@ -17,7 +17,9 @@ x = np.round((rng.standard_normal(2 * block) + 1j * rng.standard_normal(2 * bloc
 dev = DevBuf(x)
 modes = mode_mix(nrx, mix)
 tunes = tune_offsets(nrx, fs)
-eng = Engine(fs, n_receivers=nrx, max_block=block, fp32=bool(int(os.environ.get("QK_FP32", "0"))))
+fftN = int(os.environ.get("QK_FFT", "0"))            # QK_FFT=1048576: a windowed FFT frame of every block beside the receivers
+kw = dict(fft_size=fftN, data_width=4096) if fftN else {}
+eng = Engine(fs, n_receivers=nrx, max_block=block, fp32=bool(int(os.environ.get("QK_FP32", "0"))), **kw)
 for r in range(nrx):
     fi, fq, bw, off = rx_filter(fs, int(modes[r]))
     eng.set_mode(r, int(modes[r])); eng.set_tune(r, int(tunes[r])); eng.set_filters(r, fi, fq, bw, off)

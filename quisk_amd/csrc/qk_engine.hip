@@ -163,6 +163,9 @@ struct qk_engine {
     int fe_slots = 2304;       // resident one-wave workgroups of k_frontend_wave on the whole chip (occupancy query)
     int fe_share = 100;        // percent of the resident slots the front end may occupy (QK_FE_SHARE)
     int fe_rounds = 2;         // front-end workgroups launched per resident slot (QK_FE_ROUNDS)
+    bool fuse_chains = true;   // short blocks: a class chain as one launch (k_chain_fused; QK_FUSE=0 keeps the separate kernels)
+    int fuse_max_in = 4096;    // ... up to this many samples per receiver behind the decimators (QK_FUSE_MAX)
+    bool fe_packed = true;     // fp32 mode: the packed-FP32 front end k_frontend_pk (QK_FE_PACKED=0: the plane-per-lane float form)
     int rate_case = 0;
     // input
     double2 *d_in = nullptr;
@@ -885,12 +888,16 @@ static int init_receivers(qk_engine *e)
     e->H = (44 << e->S) + (1 << e->S) + 128;
     if (const char *v = getenv("QK_FE_SHARE")) e->fe_share = std::max(5, std::min(100, atoi(v)));
     if (const char *v = getenv("QK_FE_ROUNDS")) e->fe_rounds = std::max(1, std::min(16, atoi(v)));
+    if (const char *v = getenv("QK_FE_PACKED")) e->fe_packed = atoi(v) != 0;
+    if (const char *v = getenv("QK_FUSE")) e->fuse_chains = atoi(v) != 0;
+    if (const char *v = getenv("QK_FUSE_MAX")) e->fuse_max_in = std::max(1, atoi(v));
     {
         int per_cu = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg.device) == hipSuccess) cus = prop.multiProcessorCount;
         hipError_t oe = hipErrorUnknown;
-#define QK_OCC(SS) case SS: oe = e->fp32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<SS, float>, 64, 0) \
+#define QK_OCC(SS) case SS: oe = e->fp32 ? (e->fe_packed ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_pk<SS>, 64, 0) \
+                                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<SS, float>, 64, 0)) \
                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_frontend_wave<SS, double>, 64, 0); break
         switch (e->S) {
         QK_OCC(1); QK_OCC(2); QK_OCC(3); QK_OCC(4); QK_OCC(5);
@@ -1615,8 +1622,35 @@ static int measure_freq_block(qk_engine *e, const Stream &dec)
 }
 
 // run one chain over `nlist` receivers; `input` is the stream feeding stage.in == -1
+// May this run of a chain go out as one launch (k_chain_fused)?  Short blocks only (one workgroup per receiver does all the
+// work), chains made of the stage kinds the kernel knows, and none of the audio hooks that are kernels of their own.
+static bool chain_fusable(const qk_engine *e, const Chain &c, const Stream &input)
+{
+    if (!e->fuse_chains || &c == &e->front || input.n <= 0 || input.n > e->fuse_max_in) return false;
+    if ((int)c.stages.size() + 2 > QK_FUSED_MAX) return false;
+    for (const auto &st : c.stages) {
+        if (st.kind == ST_RESAMP || st.in_after || st.out_after) return false;
+        if (st.kind == ST_FIR && (e->fp32 && st.hf ? false : st.h == nullptr)) return false;
+        if (st.hook) {
+            if (e->any_notch || (st.hook == 1 && e->ssb_sq_enabled)) return false;
+            if (st.hook == 1 && &c == &e->cls_chain[CL_SSB] && !c.members.empty() && c.members[0] == 0 && e->mode[0] == QK_LSB &&
+                !(e->ag_inited && e->ag_ready)) return false;                     // the audio graph is still collecting frames
+        }
+    }
+    return true;
+}
+
 static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_list, int nlist, hipStream_t cs)
 {
+    const bool fuse = chain_fusable(e, c, input);
+    FusedArgs fz{};
+    Chain::FracSlot *frac_slot_used = nullptr;
+    double ma_close = 0;
+    auto fz_add = [&](int kind, const StreamView &in_v, const StreamView &out_v, int planes, int n_in, int n_out) -> FStage & {
+        FStage &f = fz.st[fz.nst++];
+        f.kind = kind; f.in = in_v; f.out = out_v; f.planes = planes; f.n_in = n_in; f.n_out = n_out;
+        return f;
+    };
     for (auto &st : c.stages) {
         const Stream &in = st.in < 0 ? input : c.streams[st.in];
         Stream &out = c.streams[st.out];
@@ -1631,7 +1665,11 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             const int first = st.D - 1 - phase;
             phase = (phase + n_in) % st.D;
             out.n = n_out;
-            if (n_out > 0) {
+            if (n_out > 0 && fuse) {
+                FStage &f = fz_add(FS_FIR, in_v, out_v, in.planes, n_in, n_out);
+                f.h = (e->fp32 && st.hf) ? (const void *)st.hf : (const void *)st.h; f.sub = (e->fp32 && st.hf) ? 1 : 0;
+                f.D = st.D; f.TQP = st.TQP; f.first = first;
+            } else if (n_out > 0) {
                 const bool f32 = e->fp32 && st.hf;
                 FirTArgs a{in_v, out_v, f32 ? (const void *)st.hf : (const void *)st.h, st.TQP, first, n_out, d_list};
                 Timer tm(e, st.timer, cs);
@@ -1657,7 +1695,10 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         }
         case ST_INTERP: {
             out.n = n_in * st.L;
-            if (out.n > 0) {
+            if (out.n > 0 && fuse) {
+                FStage &f = fz_add(FS_INTERP, in.view(), out.view(), 1, n_in, out.n);
+                f.h = st.h; f.T = st.T; f.L = st.L; f.delay = 0;
+            } else if (out.n > 0) {
                 InterpArgs a{in.view(), out.view(), st.h, st.T, st.L, n_in, d_list, (st.delayed && e->ssb_sq_enabled) ? SSQ_N : 0};
                 Timer tm(e, st.timer, cs);
                 hipLaunchKernelGGL(k_interp, grid1(out.n, 1, nlist), dim3(256), 0, cs, a);
@@ -1666,7 +1707,9 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         }
         case ST_HBINT: {
             out.n = n_in * 2;
-            if (n_in > 0) {
+            if (n_in > 0 && fuse) {
+                fz_add(FS_HBINT, in.view(), out.view(), in.planes, n_in, out.n).delay = 0;
+            } else if (n_in > 0) {
                 HbInterpArgs a{in.view(), out.view(), n_in, d_list, (st.delayed && e->ssb_sq_enabled) ? SSQ_N : 0};
                 Timer tm(e, st.timer, cs);
                 hipLaunchKernelGGL(k_hb_interp, grid1(n_in, in.planes, nlist), dim3(256), 0, cs, a);
@@ -1689,7 +1732,9 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         case ST_RXF: {
             out.n = n_in;
             st.total_in += n_in;
-            if (n_in > 0) {
+            if (n_in > 0 && fuse) {
+                fz_add(FS_RXF, in.view(), out.view(), 2, n_in, n_in).sub = st.rxf_kind;
+            } else if (n_in > 0) {
                 RxfArgs a{in.view(), out.view(), e->fp32 ? (const void *)e->d_taps_f : (const void *)e->d_taps, e->d_ntaps, e->d_mode, e->tap_cap, n_in,
                           st.rxf_kind, d_list};
                 Timer tm(e, st.timer, cs);
@@ -1704,7 +1749,9 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         }
         case ST_FMDISC: {
             out.n = n_in;
-            if (n_in > 0) {
+            if (n_in > 0 && fuse) {
+                fz_add(FS_FMDISC, in.view(), out.view(), 2, n_in, n_in).fs = st.fs;
+            } else if (n_in > 0) {
                 const int np = (n_in + 255) / 256;      // = grid1's x extent
                 FmDiscArgs a{in.view(), out.view(), n_in, st.fs, d_list, e->d_sq_partial, e->sq_pstride};
                 Timer tm(e, st.timer, cs);
@@ -1718,7 +1765,10 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         }
         case ST_IIR: {
             out.n = n_in;
-            if (n_in > 0) {
+            if (n_in > 0 && fuse) {
+                FStage &f = fz_add(FS_IIR, in.view(), out.view(), 1, n_in, n_in);
+                f.sub = st.iir_kind; f.a0 = st.a0; f.a1 = st.a1; f.b1 = st.b1; f.iir_state = st.iir_state;
+            } else if (n_in > 0) {
                 IirArgs a{in.view(), out.view(), n_in, st.iir_kind, st.a0, st.a1, st.b1, st.iir_state, d_list, nlist};
                 Timer tm(e, st.timer, cs);
                 hipLaunchKernelGGL(k_serial_iir, dim3(nlist), dim3(64), 0, cs, a);
@@ -1743,13 +1793,18 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
                 } else c.frac_dindex -= 1;
             }
             out.n = n_out;
-            if (n_out > 0) {
+            if (n_out > 0 && fuse) {
+                // the fused kernel reads the positions where the host wrote them; the slot's event is recorded behind it
+                fz_add(FS_FRAC, in.view(), out.view(), out.planes, n_in, n_out);
+                fz.frac_idx = fs.idx; fz.frac_pos = fs.pos;
+                frac_slot_used = &fs;
+            } else if (n_out > 0) {
                 hipLaunchKernelGGL(k_stage_frac, dim3((n_out + 255) / 256), dim3(256), 0, cs, fs.idx, fs.pos,
                                    c.d_frac_idx, c.d_frac_pos, n_out);
                 HIPCHECK(hipEventRecord(fs.ev, cs));
                 fs.used = true;
             }
-            if (n_out > 0) {
+            if (n_out > 0 && !fuse) {
                 FracArgs a{in.view(), out.view(), c.d_frac_idx, c.d_frac_pos, n_out, d_list};
                 Timer tm(e, st.timer, cs);
                 hipLaunchKernelGGL(k_fracdecim, grid1(n_out, out.planes, nlist), dim3(256), 0, cs, a);
@@ -1760,15 +1815,17 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         if (st.out == c.shared && !st.out_after) c.shared_n1 = out.n;     // the first user's samples of this block are in
         if (st.measure_div > 0 && out.n > 0 && d_list && !c.members.empty() && c.members[0] == 0) {
             // measure_audio: bank 0 only (quisk.c:1787-1790, 1873-1876, 1901-1904, 1980-1985, 2015-2018)
-            hipLaunchKernelGGL(k_measure_sum, dim3(1), dim3(256), 0, cs, out.view(), out.planes, out.n, e->d_ma);
+            if (fuse) fz_add(FS_MEASURE, out.view(), out.view(), out.planes, out.n, out.n);
+            else hipLaunchKernelGGL(k_measure_sum, dim3(1), dim3(256), 0, cs, out.view(), out.planes, out.n, e->d_ma);
             e->ma_count += out.n;
             const double fsr = (double)(e->decim_srate / st.measure_div);
             if ((double)e->ma_count >= fsr * e->ma_time) {
-                hipLaunchKernelGGL(k_measure_close, dim3(1), dim3(1), 0, cs, e->d_ma, (double)e->ma_count);
+                ma_close = (double)e->ma_count;        // (behind the fused launch, if there is one)
+                if (!fuse) hipLaunchKernelGGL(k_measure_close, dim3(1), dim3(1), 0, cs, e->d_ma, ma_close);
                 e->ma_count = 0;
             }
         }
-        if (st.hook && out.n > 0) {
+        if (st.hook && out.n > 0 && !fuse) {
             const int rate = e->decim_srate / st.hook_div;
             const bool cw = &c == &e->cls_chain[CL_CW];
             if (e->any_notch) {
@@ -1787,6 +1844,19 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         }
     }
     if (c.shared >= 0) c.streams[c.shared].n += c.shared_n1;      // what the ring took in this block: both users' samples
+    if (fuse && fz.nst > 0) {
+        fz.rx_list = d_list; fz.n_rx = nlist; fz.tap_cap = e->tap_cap;
+        fz.taps = e->fp32 ? (const void *)e->d_taps_f : (const void *)e->d_taps; fz.ntaps = e->d_ntaps; fz.mode = e->d_mode;
+        fz.sq_state = e->d_sq_state; fz.sq_flag = e->d_sq_flag + (e->pipe_blocks & 1) * e->nrx; fz.sq_level = e->squelch_level;
+        fz.ma_acc = e->d_ma;
+        {
+            Timer tm(e, QK_KT_DEMOD, cs);
+            if (e->fp32) hipLaunchKernelGGL(k_chain_fused<float>, dim3(nlist), dim3(256), 0, cs, fz);
+            else hipLaunchKernelGGL(k_chain_fused<double>, dim3(nlist), dim3(256), 0, cs, fz);
+        }
+        if (frac_slot_used) { HIPCHECK(hipEventRecord(frac_slot_used->ev, cs)); frac_slot_used->used = true; }
+        if (ma_close > 0) hipLaunchKernelGGL(k_measure_close, dim3(1), dim3(1), 0, cs, e->d_ma, ma_close);
+    }
     return QK_OK;
 }
 
@@ -1807,7 +1877,8 @@ static void launch_frontend(qk_engine *e, const FrontArgs &fa, int nspans)
     // every CU's LDS and registers to the kernels of the other two streams
     int gx = nspans;
     if (e->fe_share < 100) gx = std::max(1, std::min(nspans, (int)((long long)e->fe_slots * e->fe_share / 100 / std::max(1, e->nrx))));
-    if (e->fp32) hipLaunchKernelGGL((k_frontend_wave<S, float>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
+    if (e->fp32 && e->fe_packed) hipLaunchKernelGGL((k_frontend_pk<S>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
+    else if (e->fp32) hipLaunchKernelGGL((k_frontend_wave<S, float>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
     else hipLaunchKernelGGL((k_frontend_wave<S, double>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
 }
 
@@ -1988,7 +2059,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         } else if (consumed > 0) {
             // spans: enough workgroups to fill 256 CUs several times over, but long enough that the warm-up
             // (44 * 2^S samples per span) stays a small fraction
-            const long long unit = FW_CHUNK;
+            const long long unit = (e->fp32 && e->fe_packed) ? PK_CHUNK : FW_CHUNK;
             const long long target_wgs = (long long)e->fe_rounds * e->fe_slots;
             long long want = std::max(1LL, target_wgs / std::max(1, e->nrx));
             long long span = (consumed + want - 1) / want;

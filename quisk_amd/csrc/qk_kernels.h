@@ -44,6 +44,16 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 template <class T> struct QkVec2;
 template <> struct QkVec2<double> { typedef double2 type; };
 template <> struct QkVec2<float> { typedef float2 type; };
+// One complex float sample as a 64-bit register pair (re, im): the packed FP32 operations (v_pk_add_f32, v_pk_mul_f32,
+// v_pk_fma_f32) then filter both planes with one instruction (k_frontend_pk).
+typedef float qk_f2 __attribute__((ext_vector_type(2)));
+typedef float qk_f4 __attribute__((ext_vector_type(4)));
+template <> struct QkVec2<qk_f2> { typedef qk_f4 type; };
+__device__ __forceinline__ qk_f2 fma(qk_f2 a, qk_f2 b, qk_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+template <class T> __device__ __forceinline__ T hb_c(double c) { return T(c); }
+template <> __device__ __forceinline__ qk_f2 hb_c<qk_f2>(double c) { const float f = (float)c; return qk_f2{f, f}; }
+template <class V, class T> __device__ __forceinline__ void qk_unpack2(const V &v, T &a, T &b) { a = v.x; b = v.y; }
+template <> __device__ __forceinline__ void qk_unpack2<qk_f4, qk_f2>(const qk_f4 &v, qk_f2 &a, qk_f2 &b) { a = v.lo; b = v.hi; }
 
 // The 12 half-band constants (filter.c:359-362).
 #define HB_C0 0.000018566625444266
@@ -160,6 +170,9 @@ __global__ __launch_bounds__(256) void k_mixhist_update(FrontArgs a, double2 *hi
 #ifndef FE_WAVES_PER_EU
 #define FE_WAVES_PER_EU 2
 #endif
+#ifndef FE_PRIO
+#define FE_PRIO 0
+#endif
 struct FwLayout {
     static __host__ __device__ constexpr int sub(int s) { return (FW_CHUNK >> (s + 1)) + FE_HIST + (s == 2 ? 16 : s == 4 ? 18 : 14); }   // (pads chosen so that a stage's stores into the next level's E and O arrays fall on disjoint banks)
     static __host__ __device__ constexpr int level_off(int s) { int o = 0; for (int i = 0; i < s; i++) o += 4 * sub(i); return o; }
@@ -235,10 +248,10 @@ __device__ __forceinline__ void hb45_out(const T *__restrict__ O, const T *__res
     } else if constexpr (R % 2 == 0) {         // m0 even: two-element vector reads (16 bytes in double, 8 in float)
         const V2 *po = reinterpret_cast<const V2 *>(__builtin_assume_aligned(O, sizeof(V2))) + (m0 / 2 + 1);
 #pragma unroll
-        for (int j = 0; j < (R + 22) / 2; j++) { const V2 v = po[j]; o[2 * j] = v.x; o[2 * j + 1] = v.y; }
+        for (int j = 0; j < (R + 22) / 2; j++) { const V2 v = po[j]; qk_unpack2(v, o[2 * j], o[2 * j + 1]); }
         const V2 *pe = reinterpret_cast<const V2 *>(__builtin_assume_aligned(E, sizeof(V2))) + (m0 / 2 + 6);
 #pragma unroll
-        for (int j = 0; j < R / 2; j++) { const V2 v = pe[j]; e[2 * j] = v.x; e[2 * j + 1] = v.y; }
+        for (int j = 0; j < R / 2; j++) { const V2 v = pe[j]; qk_unpack2(v, e[2 * j], e[2 * j + 1]); }
     } else if constexpr (sizeof(T) == 8 && R == 3) {
         // 24 + 3 single ds_read_b64: the compiler pairs neighbouring 8-byte reads into ds_read2_b64, which the LDS serves at
         // half the rate of ds_read_b64 (8 clk per 16 B against 2 clk per 8 B), so the loads are spelled out.  The low 32
@@ -282,18 +295,18 @@ __device__ __forceinline__ void hb45_out(const T *__restrict__ O, const T *__res
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        T acc = (o[r + 21] + o[r]) * T(HB_C0);
-        acc = fma(o[r + 20] + o[r + 1], T(HB_C1), acc);
-        acc = fma(o[r + 19] + o[r + 2], T(HB_C2), acc);
-        acc = fma(o[r + 18] + o[r + 3], T(HB_C3), acc);
-        acc = fma(o[r + 17] + o[r + 4], T(HB_C4), acc);
-        acc = fma(o[r + 16] + o[r + 5], T(HB_C5), acc);
-        acc = fma(o[r + 15] + o[r + 6], T(HB_C6), acc);
-        acc = fma(o[r + 14] + o[r + 7], T(HB_C7), acc);
-        acc = fma(o[r + 13] + o[r + 8], T(HB_C8), acc);
-        acc = fma(o[r + 12] + o[r + 9], T(HB_C9), acc);
-        acc = fma(o[r + 11] + o[r + 10], T(HB_C10), acc);
-        y[r] = fma(e[r], T(HB_C11), acc);
+        T acc = (o[r + 21] + o[r]) * hb_c<T>(HB_C0);
+        acc = fma(o[r + 20] + o[r + 1], hb_c<T>(HB_C1), acc);
+        acc = fma(o[r + 19] + o[r + 2], hb_c<T>(HB_C2), acc);
+        acc = fma(o[r + 18] + o[r + 3], hb_c<T>(HB_C3), acc);
+        acc = fma(o[r + 17] + o[r + 4], hb_c<T>(HB_C4), acc);
+        acc = fma(o[r + 16] + o[r + 5], hb_c<T>(HB_C5), acc);
+        acc = fma(o[r + 15] + o[r + 6], hb_c<T>(HB_C6), acc);
+        acc = fma(o[r + 14] + o[r + 7], hb_c<T>(HB_C7), acc);
+        acc = fma(o[r + 13] + o[r + 8], hb_c<T>(HB_C8), acc);
+        acc = fma(o[r + 12] + o[r + 9], hb_c<T>(HB_C9), acc);
+        acc = fma(o[r + 11] + o[r + 10], hb_c<T>(HB_C10), acc);
+        y[r] = fma(e[r], hb_c<T>(HB_C11), acc);
     }
 }
 
@@ -391,6 +404,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FE_WAVES_PER
     const double2 *histp = a.hist + (long long)rx * a.H;
     double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
     const long long dummy = (long long)a.out.plane_stride - a.out.hist - 1;     // last slot of the plane: never a sample
+#if FE_PRIO
+    {   // The two waves that share a SIMD get different issue priorities (from their wave slot), so that one of them
+        // fills the other's LDS waits instead of both marching in step from read block to FMA block.
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        switch (hwid & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(3); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(1); break;
+        }
+    }
+#endif
   for (int span = blockIdx.x; span < a.nspans; span += gridDim.x) {
     const long long g_lo = a.g_lo0 + (long long)span * a.span_len;
     if (g_lo >= a.g_end) break;
@@ -546,6 +572,247 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FE_WAVES_PER
     if (lane == 0 && rx == 0 && span == 0)
         printf("fe prof: mix %lld st0 %lld st1 %lld st2 %lld st3 %lld st4 %lld carry %lld looptail %lld\n", fp[0], fp[1], fp[2], fp[3], fp[4], fp[5], fp[6], fp[7]);
 #endif
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Front end of the fp32 mode (BASELINE configs[4]) on packed FP32 operations: the same walk as k_frontend_wave -- one wave per
+// receiver x span, every level in the wave's own LDS, no barriers -- with a complex sample kept as ONE 64-bit (re, im) pair.
+// A lane then owns outputs, not a plane: 64 lanes x R outputs, chunks of 768 samples, and every half-band add and
+// multiply-add is one v_pk_add_f32 / v_pk_fma_f32 for both planes -- half the vector instructions of the plane-per-lane
+// form, whose v_fma_f32 runs at the FP64 rate.  Per level two polyphase arrays (even, odd) of (re, im) pairs, laid out and
+// padded as in FwLayout; the windows are the same 8- and 16-byte reads.  The mixer: the lane's phasor is kept in double
+// and advanced once per chunk (by p^768); inside the chunk the lane's phasor runs on in float, float(w) * float(p^64)^it, as does the
+// product with the sample (a few 1e-7 relative over the twelve samples, against the mode's 1e-5 bar).
+// ------------------------------------------------------------------------------------------------
+#define PK_CHUNK 768
+struct PkLayout {
+    static __host__ __device__ constexpr int sub(int s) { return (PK_CHUNK >> (s + 1)) + FE_HIST + (s == 2 ? 16 : s == 4 ? 18 : 14); }
+    static __host__ __device__ constexpr int level_off(int s) { int o = 0; for (int i = 0; i < s; i++) o += 2 * sub(i); return o; }
+    static __host__ __device__ constexpr int total(int S) { return level_off(S) + 16; }
+    static __host__ __device__ constexpr int R(int s) { return s == 0 ? 6 : s == 1 ? 3 : s == 2 ? 2 : 1; }
+};
+__device__ __forceinline__ qk_f2 *pk_arr(qk_f2 *smem, int s, int phase) { return smem + PkLayout::level_off(s) + phase * PkLayout::sub(s); }
+__device__ __forceinline__ qk_f2 pk_cmul(qk_f2 a, qk_f2 b)
+{
+    // (a.x b.x - a.y b.y, a.x b.y + a.y b.x) in two packed operations: the operand selects pick (a.x, a.x) x (b.x, b.y), then
+    // (a.y, a.y) x (-b.y, b.x) on top (the compiler spends two more instructions on the swap and the sign)
+    qk_f2 t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));
+    return d;
+}
+// an 8-byte LDS store that the compiler does not pair with its neighbour into ds_write2_b64
+__device__ __forceinline__ void pk_store(qk_f2 *p, qk_f2 v)
+{
+    typedef volatile __attribute__((address_space(3))) qk_f2 lds_f2;
+    *(lds_f2 *)p = v;
+}
+// carry of level s: the last 22 pairs of its two arrays go to their front (lanes 0..43 move one pair each); reads and
+// writes sit apart as in fw_carry_load / fw_carry_store
+__device__ __forceinline__ qk_f2 pk_carry_load(const qk_f2 *smem, int s, int n_new, int lane)
+{
+    const int l = lane < 44 ? lane : 43;
+    const int sub = l / 22, i = l % 22;
+    return smem[PkLayout::level_off(s) + sub * PkLayout::sub(s) + sub + n_new + i];
+}
+__device__ __forceinline__ void pk_carry_store(qk_f2 *smem, int s, int lane, qk_f2 v)
+{
+    if (lane < 44) {
+        const int sub = lane / 22, i = lane % 22;
+        smem[PkLayout::level_off(s) + sub * PkLayout::sub(s) + sub + i] = v;
+    }
+}
+template <int S, int s>
+__device__ __forceinline__ void pk_stage(qk_f2 *smem, int c, int lane, bool emit, long long obase, long long dummy,
+                                         qk_f2 (&pend_y)[PkLayout::R(S - 1)], long long (&pend_i)[PkLayout::R(S - 1)])
+{
+    constexpr int R = PkLayout::R(s);
+    const int n_out = c >> (s + 1);
+    const int m0 = lane * R;
+    if constexpr (s + 1 == S) {
+        // last level: every lane computes (idle lanes redo item 0) and hands its outputs to the chunk loop, which stores them
+        // one chunk later -- real outputs to the stream, the rest to the spare slot at its end
+        qk_f2 y[R];
+        hb45_out<qk_f2, R, true>(pk_arr(smem, s, 1), pk_arr(smem, s, 0), m0 < n_out ? m0 : 0, y);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const bool ok = emit && m0 + r < n_out;
+            pend_y[r] = y[r];
+            pend_i[r] = ok ? obase + m0 + r : dummy;
+        }
+    } else if (m0 < n_out) {
+        qk_f2 y[R];
+        hb45_out<qk_f2, R>(pk_arr(smem, s, 1), pk_arr(smem, s, 0), m0, y);
+        qk_f2 *En = pk_arr(smem, s + 1, 0), *On = pk_arr(smem, s + 1, 1);
+#pragma unroll
+        for (int r = 0; r < R; r++) {       // a partial last item spills into the arrays' padding
+            const int m = m0 + r;
+            qk_f2 *d = (m & 1) ? On : En;
+            d[FE_HIST + (m & 1) + (m >> 1)] = y[r];
+        }
+    }
+}
+
+#ifndef PK_WAVES_PER_EU
+#define PK_WAVES_PER_EU 2
+#endif
+#ifndef PK_LATE_FETCH
+#define PK_LATE_FETCH 0
+#endif
+#ifndef PK_SKIP
+#define PK_SKIP 0     // instrumented builds (outputs wrong, durations matter): 1 no prefetch, 2 no output stores, 4 no carries, 8 no mixer stores, 16 << s no level s
+#endif
+template <int S>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WAVES_PER_EU, PK_WAVES_PER_EU))) void k_frontend_pk(FrontArgs a)
+{
+    __shared__ __attribute__((aligned(16))) qk_f2 smem[PkLayout::total(S)];
+    const int rx = blockIdx.y, lane = threadIdx.x;
+    constexpr int W = FwLayout::warm(S);
+    constexpr int NIT = PK_CHUNK / 64;
+    const int mix = a.mt.mix_on[rx];
+    const double2 *histp = a.hist + (long long)rx * a.H;
+    double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
+    const long long dummy = (long long)a.out.plane_stride - a.out.hist - 1;     // last slot of the plane: never a sample
+    // p^(64 it) in float for the samples of a chunk, p^64 and p^768 in double for the lane's own phasor
+    const double2 P64 = a.mt.tabB[rx * 64 + 1], PCH = a.mt.tabB[rx * 64 + NIT];
+    const qk_f2 P64f = qk_f2{(float)P64.x, (float)P64.y};
+  for (int span = blockIdx.x; span < a.nspans; span += gridDim.x) {
+    const long long g_lo = a.g_lo0 + (long long)span * a.span_len;
+    if (g_lo >= a.g_end) break;
+    const long long g_hi = (g_lo + a.span_len < a.g_end) ? g_lo + a.span_len : a.g_end;
+    FW_SYNC();
+    for (int i = lane; i < PkLayout::level_off(S); i += 64) smem[i] = qk_f2{0.f, 0.f};
+    long long pos = g_lo - W;
+    // lanes 0..31 take the even samples of each 64, lanes 32..63 the odd ones (see k_frontend_wave)
+    const int li = ((lane & 31) << 1) | (lane >> 5);
+    qk_f2 *d0 = pk_arr(smem, 0, lane >> 5);
+    const int dofs = FE_HIST + (lane >> 5) + (lane & 31);
+    double2 w = make_double2(1.0, 0.0);
+    {
+        long long kf = pos - a.N0 + li;                // block-relative index of the lane's first sample
+        if (kf < 0) kf += ((-kf + 63) >> 6) << 6;        // first one inside this block (same lane)
+        if (mix) w = mix_w(a.mt, rx, kf);
+    }
+    double2 xv[NIT];
+    unsigned okbits = 0;
+    auto fetch = [&](long long p, int c) {
+        const long long k0 = p - a.N0;
+        if (k0 >= 0 && c == PK_CHUNK) {          // whole chunk inside this block: no clamps, no validity bits
+            const double2 *src = a.x + k0 + li;
+#pragma unroll
+            for (int it = 0; it < NIT; it++) xv[it] = src[64 * it];
+            okbits = (1u << NIT) - 1;
+            return;
+        }
+        okbits = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = li + 64 * it;
+            const long long k = k0 + i;
+            const long long hi = k + a.H;
+            const bool in_blk = k >= 0;
+            const double2 *src = in_blk ? a.x : histp;
+            long long idx = in_blk ? (k < a.n ? k : (long long)a.n - 1) : (hi > 0 ? hi : 0);
+            xv[it] = src[idx];
+            if (i < c && (in_blk || hi >= 0)) okbits |= 1u << it;
+        }
+    };
+    auto chunk_len = [&](long long p) -> int {
+        const long long lim = (p >= g_lo) ? g_hi : g_lo;
+        return (lim - p < PK_CHUNK) ? (int)(lim - p) : PK_CHUNK;
+    };
+    int c = chunk_len(pos);
+    fetch(pos, c);
+    FW_SYNC();
+    constexpr int RL = PkLayout::R(S - 1);
+    qk_f2 pend_y[RL];
+    long long pend_i[RL];
+#pragma unroll
+    for (int r = 0; r < RL; r++) { pend_y[r] = qk_f2{0.f, 0.f}; pend_i[r] = dummy; }
+    while (pos < g_hi) {
+        const bool emit = pos >= g_lo;
+        const long long k0 = pos - a.N0;
+        // ---- mix the prefetched samples into level 0 ----
+        if (k0 >= 0 && c == PK_CHUNK && mix) {      // the common case, free of per-sample conditions
+            qk_f2 wf = qk_f2{(float)w.x, (float)w.y};
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const qk_f2 xf = qk_f2{(float)xv[it].x, (float)xv[it].y};
+                if (!(PK_SKIP & 8)) pk_store(d0 + dofs + 32 * it, pk_cmul(xf, wf)); else pend_y[0] += pk_cmul(xf, wf);
+                if (it + 1 < NIT) wf = pk_cmul(wf, P64f);
+            }
+            w = cmul(w, PCH);
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int i = li + 64 * it;
+                if (i < c) {
+                    double2 v = (okbits >> it & 1u) ? xv[it] : make_double2(0.0, 0.0);
+                    if (k0 + i >= 0 && mix) { v = cmul(v, w); w = cmul(w, P64); }
+                    d0[dofs + 32 * it] = qk_f2{(float)v.x, (float)v.y};
+                }
+            }
+        }
+        // ---- the previous chunk's outputs leave, then the next chunk's samples start their trip ----
+#pragma unroll
+        for (int r = 0; r < RL; r++) { if (!(PK_SKIP & 2) || pend_y[r].x == 1.2345f) { out0[pend_i[r]] = (double)pend_y[r].x; out1[pend_i[r]] = (double)pend_y[r].y; } }
+
+        const long long npos = pos + c;
+        const int nc = npos < g_hi ? chunk_len(npos) : 0;
+#if !PK_LATE_FETCH
+        if (nc > 0 && !(PK_SKIP & 1)) fetch(npos, nc);
+#endif
+        FW_SYNC();
+        const long long obase = (pos >> S) - a.J0;
+        const bool full = c == PK_CHUNK;                 // partial chunks (warm-up tail, span end) take the safe path
+        qk_f2 cv = qk_f2{0.f, 0.f};
+        if (!(PK_SKIP & 16)) pk_stage<S, 0>(smem, c, lane, emit, obase, dummy, pend_y, pend_i);
+        FW_SYNC();
+#if PK_LATE_FETCH
+        // the next chunk's samples start their trip behind level 0, whose window (70 registers) is dead by now: the prefetch
+        // registers and the widest window are never live together, which is what lets a third wave onto the SIMD
+        if (nc > 0) fetch(npos, nc);
+#endif
+        if (full && !(PK_SKIP & 4)) cv = pk_carry_load(smem, 0, c >> 1, lane);
+#define PK_NEXT(s_) \
+        if constexpr (S > s_) { \
+            if (!(PK_SKIP & (16 << s_))) pk_stage<S, s_>(smem, c, lane, emit, obase, dummy, pend_y, pend_i); \
+            FW_SYNC(); \
+            if (full && !(PK_SKIP & 4)) { pk_carry_store(smem, s_ - 1, lane, cv); cv = pk_carry_load(smem, s_, c >> (s_ + 1), lane); } \
+        }
+        PK_NEXT(1) PK_NEXT(2) PK_NEXT(3) PK_NEXT(4)
+#undef PK_NEXT
+        if (full && !(PK_SKIP & 4)) pk_carry_store(smem, S - 1, lane, cv);
+        if (!full) {
+            // generic carry with a fence between the reads and the writes (source and destination may overlap)
+            constexpr int NC = S * 2 * FE_HIST;
+            qk_f2 keep[(NC + 63) / 64];
+#pragma unroll
+            for (int u = 0; u < (NC + 63) / 64; u++) {
+                const int wi = lane + 64 * u;
+                if (wi < NC) {
+                    const int s = wi / (2 * FE_HIST), rem = wi % (2 * FE_HIST);
+                    const int sub = rem / FE_HIST, i = rem % FE_HIST;
+                    keep[u] = pk_arr(smem, s, sub)[(c >> (s + 1)) + sub + i];
+                }
+            }
+            FW_SYNC();
+#pragma unroll
+            for (int u = 0; u < (NC + 63) / 64; u++) {
+                const int wi = lane + 64 * u;
+                if (wi < NC) {
+                    const int s = wi / (2 * FE_HIST), rem = wi % (2 * FE_HIST);
+                    const int sub = rem / FE_HIST, i = rem % FE_HIST;
+                    pk_arr(smem, s, sub)[sub + i] = keep[u];
+                }
+            }
+        }
+        FW_SYNC();
+        pos = npos; c = nc;
+    }
+#pragma unroll
+    for (int r = 0; r < RL; r++) { out0[pend_i[r]] = (double)pend_y[r].x; out1[pend_i[r]] = (double)pend_y[r].y; }
   }
 }
 
@@ -838,11 +1105,9 @@ __global__ __launch_bounds__(256) void k_fm_squelch(SquelchArgs a)
 // (|lambda| < 1: errors do not grow), inside the 1e-9 contract; a serial walk of 32768 samples per receiver took 0.65 ms.
 #define IIR_K 16
 struct IirArgs { StreamView in, out; int n, kind; double a0, a1, b1; double *state; const int *rx_list; int n_rx; };
-__global__ __launch_bounds__(64) void k_serial_iir(IirArgs a)
+__device__ __forceinline__ void serial_iir_wave(const IirArgs &a, const int rx, const int lane)
 {
 #pragma clang fp contract(off)
-    const int lane = threadIdx.x;
-    const int rx = a.rx_list ? a.rx_list[blockIdx.x] : blockIdx.x;
     const double *__restrict__ p = sv_ptr(a.in, rx, 0);
     double *__restrict__ o = sv_ptr(a.out, rx, 0);
     const double lam = a.kind == 0 ? 0.99 : -a.b1;
@@ -917,6 +1182,10 @@ __global__ __launch_bounds__(64) void k_serial_iir(IirArgs a)
         if (a.kind == 0) a.state[2 * rx] = S;
         else { a.state[2 * rx] = xprev; a.state[2 * rx + 1] = S; }
     }
+}
+__global__ __launch_bounds__(64) void k_serial_iir(IirArgs a)
+{
+    serial_iir_wave(a, a.rx_list ? a.rx_list[blockIdx.x] : blockIdx.x, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2010,6 +2279,192 @@ __global__ void k_measure_close(double *acc, double count)
     acc[1] = sqrt(acc[0] / count) / QK_CLIP32 * 1e6;
     acc[0] = 0.0;
 }
+// ------------------------------------------------------------------------------------------------
+// A class chain in ONE launch, for blocks that leave a receiver a few thousand samples at most behind the decimators: the
+// string of a dozen short kernels (FIR / 2, band-pass + detector, one-pole filters, interpolators, fractional decimator ...)
+// is launch-latency-bound there -- 5 to 10 us of queue time per kernel for a few hundred samples each -- and sits on the
+// block's critical path.  One workgroup per receiver walks the chain's stages; a stage's outputs go to the same streams in
+// HBM as in the separate kernels (they stay in L2), a workgroup barrier stands where the kernel boundary was.  Every output
+// is computed by the same operations in the same order as in k_fir_tiled / k_rxf_tiled / k_interp / k_hb_interp /
+// k_fracdecim / k_fm_disc + k_fm_squelch / k_serial_iir / k_measure_sum, so that a stream does not depend on which path a
+// block took.  (The host keeps the per-stage bookkeeping -- decimation phases, counts, the fractional decimator's
+// positions -- exactly as for the separate launches: run_chain.)
+// ------------------------------------------------------------------------------------------------
+enum { FS_FIR = 0, FS_INTERP, FS_HBINT, FS_RXF, FS_FMDISC, FS_IIR, FS_FRAC, FS_MEASURE };
+struct FStage {
+    StreamView in, out;
+    const void *h;             // FS_FIR: permuted taps in the compute type; FS_INTERP: taps (double)
+    double *iir_state;
+    double a0, a1, b1, fs;
+    int kind, planes, n_in, n_out, D, L, T, TQP, first, delay, sub, pad;
+};
+#define QK_FUSED_MAX 14
+struct FusedArgs {
+    int nst, tap_cap, n_rx, sq_pstride;
+    const int *rx_list;
+    const void *taps; const int *ntaps; const int *mode;            // FS_RXF (see RxfArgs)
+    double *sq_state; int *sq_flag; double sq_level;                // FM squelch (see SquelchArgs)
+    const int *frac_idx; const double *frac_pos;                    // FS_FRAC: positions in host memory the device can read
+    double *ma_acc;                                                 // FS_MEASURE
+    FStage st[QK_FUSED_MAX];
+};
+template <class T>
+__global__ __launch_bounds__(256) void k_chain_fused(FusedArgs a)
+{
+    __shared__ double red[256];
+    __shared__ double part[256];
+    const int rx = a.rx_list ? a.rx_list[blockIdx.x] : blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int s = 0; s < a.nst; s++) {
+        const FStage &st = a.st[s];
+        switch (st.kind) {
+        case FS_FIR: {          // fir_tile: branch by branch, taps in order, one fma each
+            const T *__restrict__ hp = static_cast<const T *>(st.h);
+            const int D = st.D, TQP = st.TQP;
+            for (int o = tid; o < st.planes * st.n_out; o += 256) {
+                const int plane = o / st.n_out, j = o - plane * st.n_out;
+                const double *__restrict__ x = sv_ptr(st.in, rx, plane) + st.first + D * j;
+                T acc = T(0);
+                for (int p = 0; p < D; p++) {
+                    const T *__restrict__ h = hp + p * TQP;
+                    const double *__restrict__ xp = x - p;
+                    for (int q = 0; q < TQP; q++) acc = fma((T)xp[-D * q], h[q], acc);
+                }
+                sv_ptr(st.out, rx, plane)[j] = (double)acc;
+            }
+            break;
+        }
+        case FS_RXF: {          // k_rxf_tiled
+            const int N = a.ntaps[rx];
+            const T *__restrict__ fi = static_cast<const T *>(a.taps) + (long long)rx * 2 * a.tap_cap;
+            const T *__restrict__ fq = (st.sub == 0) ? fi + a.tap_cap : fi;
+            const int TQP = (N + FT_QB - 1) / FT_QB * FT_QB;
+            const int m = a.mode[rx];
+            const bool lower = (m == 0 /*CWL*/ || m == 2 /*LSB*/ || m == 8 /*DGT_L*/);
+            const double *__restrict__ pr = sv_ptr(st.in, rx, 0), *__restrict__ pi = sv_ptr(st.in, rx, 1);
+            double *o0 = sv_ptr(st.out, rx, 0);
+            for (int j = tid; j < st.n_in; j += 256) {
+                T ar, ai;
+                if (N == 0) { ar = (T)pr[j]; ai = (T)pi[j]; }
+                else {
+                    ar = T(0); ai = T(0);
+                    for (int q = 0; q < TQP; q++) ar = fma((T)pr[j - q], fi[q], ar);
+                    for (int q = 0; q < TQP; q++) ai = fma((T)pi[j - q], fq[q], ai);
+                }
+                if (st.sub == 0) o0[j] = (double)(lower ? ar + ai : ar - ai);
+                else if (st.sub == 1) o0[j] = hypot((double)ar, (double)ai);
+                else { o0[j] = (double)ar; sv_ptr(st.out, rx, 1)[j] = (double)ai; }
+            }
+            break;
+        }
+        case FS_INTERP: {       // k_interp
+            const double *__restrict__ h = static_cast<const double *>(st.h);
+            const int terms = st.T / st.L;
+            for (int o = tid; o < st.n_in * st.L; o += 256) {
+                const int i = o / st.L, jj = o - i * st.L;
+                const double *__restrict__ p = sv_ptr(st.in, rx, 0) + i - st.delay;
+                double acc = 0.0;
+                for (int k = 0; k < terms; k++) acc = fma(p[-k], h[jj + k * st.L], acc);
+                sv_ptr(st.out, rx, 0)[o] = acc * st.L;
+            }
+            break;
+        }
+        case FS_HBINT: {        // k_hb_interp
+            for (int o = tid; o < st.planes * st.n_in; o += 256) {
+                const int plane = o / st.n_in, i = o - plane * st.n_in;
+                const double *__restrict__ p = sv_ptr(st.in, rx, plane) + i - st.delay;
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 11; k++) acc = fma(p[-k] + p[-21 + k], c_hb45[k], acc);
+                double *o2 = sv_ptr(st.out, rx, plane) + 2 * (long long)i;
+                o2[0] = p[-11] * HB_C11 * 2;
+                o2[1] = acc * 2;
+            }
+            break;
+        }
+        case FS_FRAC: {         // k_fracdecim
+#pragma clang fp contract(off)
+            for (int o = tid; o < st.planes * st.n_out; o += 256) {
+                const int plane = o / st.n_out, m = o - plane * st.n_out;
+                const double *__restrict__ p = sv_ptr(st.in, rx, plane) + a.frac_idx[m];
+                const double d = a.frac_pos[m];
+                const double c0 = p[-3], c1 = p[-2], c2 = p[-1], c3 = p[0];
+                const double xm0 = d - 0, xm1 = d - 1, xm2 = d - 2, xm3 = d - 3;
+                sv_ptr(st.out, rx, plane)[m] = (xm1 * xm2 * xm3 * c0 / -6.0 + xm0 * xm2 * xm3 * c1 / 2.0 +
+                                                xm0 * xm1 * xm3 * c2 / -2.0 + xm0 * xm1 * xm2 * c3 / 6.0);
+            }
+            break;
+        }
+        case FS_FMDISC: {       // k_fm_disc, then k_fm_squelch: sums of |c| over groups of 256 samples, trees in the same order
+            const int np = (st.n_in + 255) / 256;
+            for (int g = 0; g < np; g++) {
+                const int i = g * 256 + tid;
+                double mag = 0.0;
+                if (i < st.n_in) {
+                    const double *pr = sv_ptr(st.in, rx, 0) + i, *pi = sv_ptr(st.in, rx, 1) + i;
+                    const double cr = pr[0], ci = pi[0], qr = pr[-1], qi = pi[-1];
+                    const double re = cr * qr + ci * qi;
+                    const double im = ci * qr - cr * qi;
+                    sv_ptr(st.out, rx, 0)[i] = st.fs * atan2(im, re);
+                    mag = hypot(cr, ci);
+                }
+                red[tid] = mag;
+                __syncthreads();
+                for (int o = 128; o > 0; o >>= 1) {
+                    if (tid < o) red[tid] += red[tid + o];
+                    __syncthreads();
+                }
+                if (tid == 0) part[g] = red[0];
+                __syncthreads();
+            }
+            red[tid] = tid < np ? part[tid] : 0.0;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if (tid < o) red[tid] += red[tid + o];
+                __syncthreads();
+            }
+            if (tid == 0) {
+                double *sq = a.sq_state + 3 * rx;
+                double sum = sq[0] + red[0], cnt = sq[1] + st.n_in, db = sq[2];
+                if (cnt >= 2400.0) {
+                    db = sum / cnt / QK_CLIP32;
+                    db = db > 1.E-10 ? 20 * log10(db) : -200.0;
+                    sum = 0.0; cnt = 0.0;
+                }
+                sq[0] = sum; sq[1] = cnt; sq[2] = db;
+                a.sq_flag[rx] = db < a.sq_level;
+            }
+            break;
+        }
+        case FS_IIR: {          // k_serial_iir: one wave
+            if (tid < 64) {
+                const IirArgs ia{st.in, st.out, st.n_in, st.sub, st.a0, st.a1, st.b1, st.iir_state, nullptr, a.n_rx};
+                serial_iir_wave(ia, rx, tid);
+            }
+            break;
+        }
+        case FS_MEASURE: {      // k_measure_sum: receiver 0's workgroup only
+            if (rx == 0) {
+                double sm = 0.0;
+                for (int pl = 0; pl < st.planes; pl++) {
+                    const double *p = sv_ptr(st.in, 0, pl);
+                    for (int i = tid; i < st.n_in; i += 256) sm += p[i] * p[i];
+                }
+                red[tid] = sm;
+                __syncthreads();
+                for (int o = 128; o > 0; o >>= 1) {
+                    if (tid < o) red[tid] += red[tid + o];
+                    __syncthreads();
+                }
+                if (tid == 0) a.ma_acc[0] += red[0];
+            }
+            break;
+        }
+        }
+        __syncthreads();
+    }
+}
+
 // Frames for the audio graph (quisk_calc_audio_graph, quisk.c:903-964) and for measure_freq (quisk.c:4850-4920): `take` samples
 // of receiver 0's stream (plane 1 may be absent: a real stream) go to frame[index ...], each divided by `scale`
 __global__ __launch_bounds__(256) void k_frame_collect(StreamView in, int planes, int first, int take, double2 *frame, int index, double scale)
