@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 
 #define QK_CLIP32 2147483647.0
 
@@ -1351,15 +1352,118 @@ struct __attribute__((aligned(16))) AgcSlot {
 // the state (NaN gain) rather than hang the GPU.  Control flow is kept flat on purpose (one loop, one chain of
 // ifs, no early exits): a taken branch costs this single wave some twenty cycles, and the compiler's loop-exit
 // unification turns `continue` / `return` into many of them.
-#define AGC_RING 4
+#define AGC_RING 16
 #define AGC_CHUNK 32
 #define AGC_SPIN_LIMIT (1 << 22)
 #define AGC_LDS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// a 32-bit LDS store from lane 0 alone, without a branch the compiler can see
+__device__ __forceinline__ void lds_store_lane0(const unsigned addr, const int v)
+{
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t" "s_mov_b64 exec, 1\n\t" "ds_write_b32 %[a], %[v]\n\t" "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(sv) : [a] "v"(addr), [v] "v"(v) : "memory");
+}
+// The walker's view of a ring slot in ONE trip to the LDS: the tag first, then the record, the tile's gains and its |x| -- the
+// LDS executes a wave's reads in the order they were issued and the runner wrote the tag last, so a tag that is the wanted one
+// vouches for what was read behind it.  (A tag read and a dependent second read cost this wave two LDS latencies per tile,
+// each several hundred cycles beside the front end's traffic.)
+typedef double qk_d2 __attribute__((ext_vector_type(2)));
+typedef int qk_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void agc_take(const unsigned a_rec, const unsigned a_gv, const unsigned a_mv, int &tag, qk_d2 &r0, qk_i4 &r1,
+                                         double &gv, double &mv)
+{
+    asm volatile("ds_read_b32 %[tg], %[ar] offset:32\n\t" "ds_read_b128 %[r0], %[ar]\n\t" "ds_read_b128 %[r1], %[ar] offset:16\n\t"
+                 "ds_read_b64 %[gv], %[ag]\n\t" "ds_read_b64 %[mv], %[am]\n\t" "s_waitcnt lgkmcnt(0)"
+                 : [tg] "=&v"(tag), [r0] "=&v"(r0), [r1] "=&v"(r1), [gv] "=&v"(gv), [mv] "=&v"(mv)
+                 : [ar] "v"(a_rec), [ag] "v"(a_gv), [am] "v"(a_mv) : "memory");
+}
+// The runner's tight loop -- whole PLAIN tiles j .. jend-1 of the chunk in LDS, no clip, no window boundary -- as one block of
+// assembly.  A lone wave issues in order, so every instruction between two chains is time on top of the recurrence's own
+// latency; here the only ones left behind a chain are the 64th step (readlane, mul, add: the next tile's first gain), the ring
+// test and a handful of moves.  Everything else rides in the shadow of a chain's dependent operations or ahead of it:
+//   - a tile's hand-over (its 64 gains, step constant, end gain, tag -- the tag last) is DEFERRED to the head of the next tile's
+//     pass, where the LDS takes the four stores while the chain runs (the first pass writes to a spare slot nobody reads; the
+//     last tile's hand-over follows the loop);
+//   - the walker's progress word and the tile's maximum of |x| (made by the fetcher) are asked for in front of the chain and
+//     looked at behind it;
+//   - slot addresses and the tag of the tile are scalar arithmetic between the chain's first steps.
+// The record goes out from lane 0 alone (exec = 1, then -2 = the chain's first shift: no extra instruction).  Leaves with j at
+// the first tile not made: jend, or the tile whose ring test failed (ring full or a restart: the general step deals with it; that
+// tile's chain is dropped, as before).  Registers v108-v123 and s44-s51 are the block's own (clobbers); wait states between a
+// VALU write of an SGPR / VGPR and its readers are the gfx940 family's (2 and 1), kept by instruction order plus s_nop.
+#define AGC_T1 "s_lshl_b64 exec, exec, 1\n\t" "v_mul_f64 v[108:109], v[108:109], %[k]\n\t" "v_add_f64 v[108:109], v[108:109], %[t]\n\t"
+#define AGC_T4 AGC_T1 AGC_T1 AGC_T1 AGC_T1
+#define AGC_T16 AGC_T4 AGC_T4 AGC_T4 AGC_T4
+#define AGC_HANDOVER "ds_write_b64 v115, v[110:111]\n\t" "s_mov_b64 exec, 1\n\t" "ds_write_b64 v116, %[t]\n\t" \
+                     "ds_write_b64 v116, %[g0] offset:8\n\t" "ds_write_b32 v116, v117 offset:32\n\t"
+__device__ __forceinline__ void agc_tight_run(double &g0, const double keep, const double add, double &rmax, int &j, const int jend,
+                                              const int gensh, const int taghi, const unsigned a_gv0, const unsigned a_rec0,
+                                              const unsigned a_gv_spare, const unsigned a_rec_spare, const unsigned a_wstat,
+                                              const unsigned a_tmax)
+{
+    asm volatile(
+        "v_mov_b32 v115, %[agvs]\n\t" "v_mov_b32 v116, %[arecs]\n\t" "v_mov_b32 v117, -1\n\t" "v_mov_b32 v118, %[atm]\n\t"
+        "v_mov_b64 v[110:111], %[g0]\n\t"
+        "1:\n\t"
+        "ds_read_b32 v114, %[aw]\n\t"
+        "ds_read_b64 v[112:113], v118\n\t"
+        AGC_HANDOVER
+        "s_mov_b64 exec, -1\n\t"
+        "v_mov_b64 v[108:109], %[g0]\n\t"
+        "s_mov_b64 exec, -2\n\t"
+        "v_mul_f64 v[108:109], v[108:109], %[k]\n\t" "v_add_f64 v[108:109], v[108:109], %[t]\n\t"
+        AGC_T1 AGC_T1
+        "s_and_b32 s46, %[j], %[ringm1]\n\t"
+        AGC_T1
+        "s_lshl_b32 s48, s46, 9\n\t"
+        AGC_T1
+        "s_mul_i32 s49, s46, 48\n\t"
+        AGC_T1
+        "s_add_i32 s49, s49, %[arec0]\n\t"
+        AGC_T1
+        "s_or_b32 s50, %[taghi], %[j]\n\t"
+        AGC_T1
+        "s_add_i32 s51, %[j], %[gensh]\n\t"
+        AGC_T1 AGC_T4 AGC_T16 AGC_T16 AGC_T16 AGC_T1 AGC_T1
+        "s_mov_b64 exec, -1\n\t"
+        "s_nop 1\n\t"
+        "v_readlane_b32 s44, v108, 63\n\t"
+        "v_readlane_b32 s45, v109, 63\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 s46, v114\n\t"
+        "s_nop 0\n\t"
+        "v_mul_f64 v[122:123], %[k], s[44:45]\n\t"
+        "s_sub_i32 s51, s51, s46\n\t"
+        "s_cmp_gt_u32 s51, %[ringm1]\n\t"
+        "v_add_f64 v[122:123], v[122:123], %[t]\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "v_max_f64 %[rm], %[rm], v[112:113]\n\t"
+        "v_mov_b64 v[110:111], v[108:109]\n\t"
+        "v_add_u32 v115, s48, %[agv0]\n\t"
+        "v_mov_b32 v116, s49\n\t"
+        "v_mov_b32 v117, s50\n\t"
+        "v_add_u32 v118, 8, v118\n\t"
+        "v_mov_b64 %[g0], v[122:123]\n\t"
+        "s_add_i32 %[j], %[j], 1\n\t"
+        "s_cmp_lt_i32 %[j], %[jend]\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "3:\n\t"
+        AGC_HANDOVER
+        "s_mov_b64 exec, -1\n\t"
+        : [g0] "+v"(g0), [rm] "+v"(rmax), [j] "+s"(j)
+        : [k] "v"(keep), [t] "v"(add), [jend] "s"(jend), [gensh] "s"(gensh), [taghi] "s"(taghi), [agv0] "v"(a_gv0), [arec0] "s"(a_rec0),
+          [agvs] "v"(a_gv_spare), [arecs] "v"(a_rec_spare), [aw] "v"(a_wstat), [atm] "v"(a_tmax), [ringm1] "n"(AGC_RING - 1)
+        : "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v122", "v123",
+          "s44", "s45", "s46", "s48", "s49", "s50", "s51", "scc", "memory");
+}
+
 __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
 {
 #pragma clang fp contract(off)
-    __shared__ double sp_gv[AGC_RING][64];          // runner -> walker: the gains of tile k in slot k % AGC_RING
-    __shared__ AgcSlot sp_rec[AGC_RING];            // ... what it assumed and what it ends with, and the tag that says so
+    __shared__ double sp_gv[AGC_RING + 1][64];      // runner -> walker: the gains of tile k in slot k % AGC_RING (one spare row
+    __shared__ AgcSlot sp_rec[AGC_RING + 1];        // nobody reads); what it assumed and what it ends with, and the tag that says so
+    __shared__ double tmaxs[2][AGC_CHUNK];          // fetcher -> runner: max |x| over each tile of the chunk
+    static_assert(sizeof(AgcSlot) == 48 && offsetof(AgcSlot, end) == 8 && offsetof(AgcSlot, tag) == 32, "agc_tight_run writes these offsets");
     __shared__ int wstat;                           // walker -> runner, fetcher: restart generation << 20 | tiles finished
     __shared__ int fetched;                         // fetcher -> walker: chunks in LDS
     __shared__ double rs_g, rs_add, rs_max;         // walker -> runner, with a new generation: the true state at sample
@@ -1395,6 +1499,8 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
     // `volatile` would turn them into system-scope FLAT accesses, a trip to memory each)
     auto peek = [](int *w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto poke = [](int *w, int v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto unid = [](double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); };
+    auto lds_addr = [](const void *q) { return (unsigned)reinterpret_cast<size_t>(q); };    // (the low word of an LDS pointer is its offset)
 
     if (wave == 0) {
         // ---------------- the runner ----------------
@@ -1406,7 +1512,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
         bool alive = true;
 #ifdef AGC_PROF
         long long ap[4] = {0, 0, 0, 0}, ap_last = clock64(), ap_t0 = ap_last;
-        long long ac[4] = {0, 0, 0, 0};
+        long long ac[6] = {0, 0, 0, 0, 0, 0};
 #define AGC_COUNT(k) ac[k]++
 #define AGC_PROBE(k) do { const long long t_ = clock64(); ap[k] += t_ - ap_last; ap_last = t_; } while (0)
 #else
@@ -1448,21 +1554,14 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                 int jend = (j / AGC_CHUNK + 1) * AGC_CHUNK;
                 if (T < jend) jend = T;
                 if (j + (ahead >> 6) < jend) jend = j + (ahead >> 6);
-                const double *mp = &sm[(j / AGC_CHUNK) & 1][(j % AGC_CHUNK) * 64 + lane];
                 const int j0 = j;
-                while (j < jend) {
-                    const int ws_v = peek(&wstat);          // (asked for before the chain, looked at after it)
-                    const double mv = *mp;
+                if (j < jend) {
                     AGC_PROBE(0);
-                    const double gs = agc_chain<true>(g0, c.keep, add, 0);
+                    j = uni(j);
+                    agc_tight_run(g0, c.keep, add, rmax, j, uni(jend), uni(gen << 20), uni((int)(tag_of(gen, 0) | 0x80000000)), lds_addr(&sp_gv[0][lane]),
+                                  (unsigned)uni((int)lds_addr(&sp_rec[0])), lds_addr(&sp_gv[AGC_RING][lane]), lds_addr(&sp_rec[AGC_RING]), lds_addr(&wstat),
+                                  lds_addr(&tmaxs[(j / AGC_CHUNK) & 1][j % AGC_CHUNK]));
                     AGC_PROBE(1);
-                    const double pend = readlane_f64(gs, 63) * c.keep + add;
-                    const double nmax = walk_max(rmax, mv, true);
-                    // a restart (another generation in wstat) or the ring full: the general step deals with it
-                    if ((unsigned)(j - (uni(ws_v) - (gen << 20))) >= (unsigned)AGC_RING) break;
-                    hand_over(j, gs, add, pend, true, add, 0, 64);
-                    g0 = pend; rmax = nmax; ++j; mp += 64;
-                    AGC_PROBE(2);
                 }
                 const bool ran_out = j >= jend;     // (not: left early for the general step)
                 ir += (j - j0) << 6;
@@ -1478,6 +1577,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                     if (left < 0) left += a.buf_size;
                     bool made = true;
                     if (left < 64) {
+                        AGC_PROBE(0);
                         const int bl = left;
                         const int ws_v = peek(&wstat);
                         const double mv = sm[(j / AGC_CHUNK) & 1][(j % AGC_CHUNK) * 64 + lane];
@@ -1500,6 +1600,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                             ir += 64;
                             if (ir >= a.buf_size) ir -= a.buf_size;
                         }
+                        AGC_PROBE(2);
                     }
                     if (made) continue;             // back into the loop above (or to whatever the next tile needs)
                 }
@@ -1542,12 +1643,14 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                 ir += 64 - st;
                 if (ir >= a.buf_size) ir -= a.buf_size;
                 g0 = pend; add = add1; rmax = nmax; st = 0; ++j;
+                AGC_COUNT(4);
                 waits = 0;
             } else if (rs != gen) {                 // a restart: continue from the truth (the tile just made is dropped)
                 AGC_LDS_WAIT();
                 j = uni(rs_tile); st = uni(rs_start); clip = uni(rs_clip); ir = uni(rs_ir); is = uni(rs_is);
                 g0 = readlane_f64(rs_g, 0); add = readlane_f64(rs_add, 0); rmax = readlane_f64(rs_max, 0);
                 gen = rs;
+                AGC_COUNT(5);
                 waits = 0;
             } else {                                // ring full, chunk not there yet, or all tiles made: the walker may still restart
                 if (j >= T && w >= T) alive = false;
@@ -1559,31 +1662,51 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
             }
         }
 #ifdef AGC_PROF
-        if (lane == 0 && rx == 0) printf("agc runner: tiles %d, cycles: pre-chain %lld chain %lld post-chain %lld waiting %lld, whole wave %lld; waits: ring full %lld, chunk not fetched %lld, all made %lld; record-walk steps %lld\n", T, ap[0], ap[1], ap[2], ap[3], clock64() - ap_t0, ac[1], ac[2], ac[3], ac[0]);
+        if (lane == 0 && rx == 0) printf("agc runner: tiles %d, cycles: other %lld tight run %lld boundary tiles %lld sleeping %lld, whole wave %lld; waits: ring full %lld, chunk not fetched %lld, all made %lld; record-walk steps %lld; general-step tiles %lld, restarts %lld\n", T, ap[0], ap[1], ap[2], ap[3], clock64() - ap_t0, ac[1], ac[2], ac[3], ac[0], ac[4], ac[5]);
 #endif
     } else if (wave == 1) {
         // ---------------- the walker ----------------
         int gen = 0;
-        bool dead = false;
+        int dead = 0;                               // (read through uni(): the tests on it are wave-uniform branches)
+#ifdef AGC_PROF
+        long long wp_wait = 0, wp_waited = 0, wp_take = 0; const long long wp_t0 = clock64();
+#endif
         double cur_add = step_const(s);             // its step constant: changes only on the general path
         // what the slot of the current tile holds
-        double spec_gv = 0.0, sa = 0.0, sa1 = 0.0, se = 0.0;
+        double spec_gv = 0.0, sa = 0.0, sa1 = 0.0, se = 0.0, cur_mv = 0.0;
         int sc = 0, sb = 64;
         // wait for tile k of the current generation, take it
         auto acquire = [&](const int k) {
             const int slot = k & (AGC_RING - 1);
             const int want = tag_of(gen, k);
-            int spins = 0, tag = uni(peek(&sp_rec[slot].tag));
-            while (!dead && (tag & 0x7fffffff) != want) {
+            const unsigned a_rec = lds_addr(&sp_rec[slot]), a_gv = lds_addr(&sp_gv[slot][lane]);
+            const unsigned a_mv = lds_addr(&sm[(k / AGC_CHUNK) & 1][(k % AGC_CHUNK) * 64 + lane]);
+            int spins = 0, tagv;
+            qk_d2 r0; qk_i4 r1;
+#ifdef AGC_PROF
+            const long long wq0 = clock64();
+#endif
+            agc_take(a_rec, a_gv, a_mv, tagv, r0, r1, spec_gv, cur_mv);
+            int tag = uni(tagv);
+#ifdef AGC_PROF
+            const long long wq1 = clock64();
+            wp_take += wq1 - wq0;
+            if ((tag & 0x7fffffff) != want) wp_waited++;
+#endif
+            while (!uni(dead) && (tag & 0x7fffffff) != want) {
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > AGC_SPIN_LIMIT || uni(peek(&aborted))) dead = true;
-                tag = uni(peek(&sp_rec[slot].tag));
+                if (++spins > AGC_SPIN_LIMIT || uni(peek(&aborted))) dead = 1;
+                agc_take(a_rec, a_gv, a_mv, tagv, r0, r1, spec_gv, cur_mv);
+                tag = uni(tagv);
             }
-            asm volatile("" ::: "memory");          // (the tile's data is read after its tag, not before)
-            sa = sp_rec[slot].add; se = sp_rec[slot].end;
-            spec_gv = sp_gv[slot][lane];
+#ifdef AGC_PROF
+            wp_wait += clock64() - wq1;
+#endif
+            // (what an asm block returns is per-lane to the compiler: the record's fields are made wave-uniform again, or every
+            // test on them turns into EXEC-mask bookkeeping)
+            sa = unid(r0.x); se = unid(r0.y);
             sa1 = sa; sb = 64; sc = 0;              // a plain tile
-            if (tag >= 0) { sa1 = sp_rec[slot].add1; sb = sp_rec[slot].bl; sc = sp_rec[slot].clip; }
+            if (tag >= 0) { sa1 = __hiloint2double(uni(r1.y), uni(r1.x)); sb = uni(r1.z); sc = uni(r1.w); }
         };
         // ask the runner for tile k from sample `start` on, in the walker's state
         auto restart = [&](const int k, const int start) {
@@ -1596,7 +1719,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
             if (lane == 0) poke(&wstat, tag_of(gen, k));
         };
         auto tile = [&](const int k) {
-            const double mv = sm[(k / AGC_CHUNK) & 1][(k % AGC_CHUNK) * 64 + lane];
+            const double mv = cur_mv;               // (|x| of the tile: came with the slot)
             const int i0 = k << 6;
             const int cnt = (n_new - i0 < 64) ? n_new - i0 : 64;
             // The common tile, at the least cost: the runner's gains are valid from sample 0, not clipping, a whole
@@ -1624,7 +1747,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
             }
             double gv = 0.0;                                            // gain in force at this lane's sample
             int start = 0;
-            while (start < cnt && !dead) {
+            while (start < cnt && !uni(dead)) {
                 s.pad++;                                                // statistics: speculation passes
                 const bool mine = lane >= start && lane < cnt;
                 // The runner's gains serve from `start` on when the state there is the one its chain passed through at
@@ -1681,20 +1804,62 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
             // only make a wrong target at the next boundary, which is caught there like any other.)
             if (!uni((int)((sc == s.is_clipping) & (sa1 == cur_add) & (se == s.gain))) && k + 1 < T) restart(k + 1, 0);
         };
-        for (int k = 0; k < T && !dead; ++k) {
+        const int T_whole = n_new >> 6;             // tiles of 64 samples
+        int f_seen = 0;                             // chunks known to be in LDS
+        for (int k = 0; k < T && !uni(dead); ++k) {
+            // ---- the quiet run: PLAIN tiles (no clip, no window boundary, the runner's step constant and gain are the walker's)
+            // one after the other in a loop of a few dozen instructions.  The kernel is tens of KiB of code and shares its
+            // instruction cache with the front end's; a tile that walks through acquire() and tile() below touches a dozen cache
+            // lines far apart, and measured 1100 cycles against the 400 its instructions take.  Whatever this loop does not
+            // like -- a tile that is not there yet, not plain, a chunk not fetched, a clip -- it leaves to the general code.
+            if (!s.is_clipping) {
+                int ahead = s.index_start - s.index_read;
+                if (ahead < 0) ahead += a.buf_size;
+                int kend = k + (ahead >> 6);                    // whole tiles in front of the window boundary
+                if (T_whole < kend) kend = T_whole;
+                while (k < kend) {
+                    if (k / AGC_CHUNK >= f_seen) { f_seen = uni(peek(&fetched)); if (k / AGC_CHUNK >= f_seen) break; }
+                    const int slot = k & (AGC_RING - 1);
+                    int tagv; qk_d2 r0; qk_i4 r1; double gvv, mv;
+                    agc_take(lds_addr(&sp_rec[slot]), lds_addr(&sp_gv[slot][lane]),
+                             lds_addr(&sm[(k / AGC_CHUNK) & 1][(k % AGC_CHUNK) * 64 + lane]), tagv, r0, r1, gvv, mv);
+                    if (uni(tagv) != (int)(tag_of(gen, k) | 0x80000000)) break;         // not there yet, or not a plain tile
+                    const bool quiet = (unid(r0.x) == cur_add) & (readlane_f64(gvv, 0) == s.gain) & !(mv * gvv > c.ceil_);
+                    if (__ballot(quiet) != ~0ull) break;
+                    unsigned long long over = __ballot(mv > s.themax);
+                    while (over) {
+                        s.themax = readlane_f64(mv, (int)__ffsll((long long)over) - 1);
+                        over = __ballot(mv > s.themax);
+                    }
+                    s.pad++;
+                    s.index_read += 64;
+                    if (s.index_read >= a.buf_size) s.index_read -= a.buf_size;
+                    s.gain = unid(r0.y);
+                    g[(k << 6) + lane] = gvv;
+                    ++k;
+                    lds_store_lane0(lds_addr(&wstat), tag_of(gen, k));
+                }
+            }
+            if (k >= T) break;
             if (k % AGC_CHUNK == 0) {
                 int spins = 0;
-                while (!dead && uni(peek(&fetched)) <= k / AGC_CHUNK) {
+                while (!uni(dead) && uni(peek(&fetched)) <= k / AGC_CHUNK) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > AGC_SPIN_LIMIT || uni(peek(&aborted))) dead = true;
+                    if (++spins > AGC_SPIN_LIMIT || uni(peek(&aborted))) dead = 1;
                 }
             }
             acquire(k);
-            if (!dead) tile(k);
-            if (lane == 0) poke(&wstat, tag_of(gen, k + 1));
+            if (!uni(dead)) tile(k);
+            // (lane 0 alone, by EXEC mask inside the asm: as an `if (lane == 0)` the store is a divergent branch to the compiler,
+            // which then duplicates k + 1 into its arms -- and with that one phi the whole loop, k and the state included,
+            // turns per-lane: every test in the walker became EXEC-mask bookkeeping)
+            lds_store_lane0(lds_addr(&wstat), tag_of(gen, k + 1));
         }
-        if (dead) { poke(&aborted, 1); s.gain = __builtin_nan(""); if (lane == 0 && a.abort_flag) *a.abort_flag = 1; }
+        if (uni(dead)) { poke(&aborted, 1); s.gain = __builtin_nan(""); if (lane == 0 && a.abort_flag) *a.abort_flag = 1; }
         if (lane == 0) { poke(&wstat, tag_of(gen, T)); a.state[rx] = s; }
+#ifdef AGC_PROF
+        if (lane == 0 && rx == 0) printf("agc walker: whole wave %lld cycles, of them first look at the slot %lld, waiting for it %lld (three clock reads per tile, ~100 cycles each, are in these figures); tiles it had to wait for %lld of %d; speculation passes %d\n", clock64() - wp_t0, wp_take, wp_wait, wp_waited, T, s.pad);
+#endif
     } else {
         // ---------------- the fetcher ----------------
         // Loads are unconditional (indices clamped to the block; lanes past the end are never `mine`).
@@ -1713,8 +1878,16 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                 __builtin_amdgcn_s_sleep(8);
                 if (++spins > AGC_SPIN_LIMIT || uni(peek(&aborted))) { poke(&aborted, 1); alive = false; }
             }
+            double tm = 0.0;                        // lane u: the maximum over tile u
 #pragma unroll
-            for (int u = 0; u < AGC_CHUNK; ++u) sm[ch & 1][u * 64 + lane] = fabs(v[u]);
+            for (int u = 0; u < AGC_CHUNK; ++u) {
+                double m = fabs(v[u]);
+                sm[ch & 1][u * 64 + lane] = m;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(m, off); m = o > m ? o : m; }
+                if (lane == u) tm = m;
+            }
+            if (lane < AGC_CHUNK) tmaxs[ch & 1][lane] = tm;
             AGC_LDS_WAIT();
             if (lane == 0) poke(&fetched, ch + 1);
             if (ch + 1 < nch) load_chunk(ch + 1);   // in flight while the walker works through chunk ch
