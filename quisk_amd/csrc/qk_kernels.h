@@ -1316,14 +1316,16 @@ __device__ __forceinline__ double agc_chain(double g0, double keep, double add, 
     return gv;
 }
 
-// One slot of the runner's ring, written by one lane with two 16-byte stores, the tag in the second
+// The record of a ring slot: {end, add} go out as one 16-byte store from lane 0, the tag behind them
 struct __attribute__((aligned(16))) AgcSlot {
-    double add, end;            // step constant at the tile's first sample; gain after its last
+    double end, add;            // gain after the tile's last sample; step constant at its first
     double add1;                // \ only for a tile that is not PLAIN (not clipping, no window boundary in it):
     int bl, clip;               // / step constant behind the boundary, the boundary's lane (64: none), the path
     int tag;                    // plain << 31 | generation << 20 | tile, -1 nothing
     int pad[3];
 };
+// a slot of the ring: the tile's 64 gains and its record, 1 KiB apart (agc_tight_run makes slot addresses by mask)
+struct __attribute__((aligned(1024))) AgcRingSlot { double gv[64]; AgcSlot rec; };
 // Three WAVES per receiver.  The state machine is serial in time, but almost every sample takes one of two
 // trivial paths: "not clipping, no new clip, not at the window boundary" (gain = gain*(1-tr) + target*tr,
 // themax = max(themax, m)) or "clipping, no new maximum, ramp not finished" (gain -= delta).  A tile of 64
@@ -1377,93 +1379,91 @@ __device__ __forceinline__ void agc_take(const unsigned a_rec, const unsigned a_
                  : [tg] "=&v"(tag), [r0] "=&v"(r0), [r1] "=&v"(r1), [gv] "=&v"(gv), [mv] "=&v"(mv)
                  : [ar] "v"(a_rec), [ag] "v"(a_gv), [am] "v"(a_mv) : "memory");
 }
-// The runner's tight loop -- whole PLAIN tiles j .. jend-1 of the chunk in LDS, no clip, no window boundary -- as one block of
-// assembly.  A lone wave issues in order, so every instruction between two chains is time on top of the recurrence's own
-// latency; here the only ones left behind a chain are the 64th step (readlane, mul, add: the next tile's first gain), the ring
-// test and a handful of moves.  Everything else rides in the shadow of a chain's dependent operations or ahead of it:
-//   - a tile's hand-over (its 64 gains, step constant, end gain, tag -- the tag last) is DEFERRED to the head of the next tile's
-//     pass, where the LDS takes the four stores while the chain runs (the first pass writes to a spare slot nobody reads; the
-//     last tile's hand-over follows the loop);
-//   - the walker's progress word and the tile's maximum of |x| (made by the fetcher) are asked for in front of the chain and
-//     looked at behind it;
-//   - slot addresses and the tag of the tile are scalar arithmetic between the chain's first steps.
-// The record goes out from lane 0 alone (exec = 1, then -2 = the chain's first shift: no extra instruction).  Leaves with j at
-// the first tile not made: jend, or the tile whose ring test failed (ring full or a restart: the general step deals with it; that
-// tile's chain is dropped, as before).  Registers v108-v123 and s44-s51 are the block's own (clobbers); wait states between a
-// VALU write of an SGPR / VGPR and its readers are the gfx940 family's (2 and 1), kept by instruction order plus s_nop.
-#define AGC_T1 "s_lshl_b64 exec, exec, 1\n\t" "v_mul_f64 v[108:109], v[108:109], %[k]\n\t" "v_add_f64 v[108:109], v[108:109], %[t]\n\t"
-#define AGC_T4 AGC_T1 AGC_T1 AGC_T1 AGC_T1
-#define AGC_T16 AGC_T4 AGC_T4 AGC_T4 AGC_T4
-#define AGC_HANDOVER "ds_write_b64 v115, v[110:111]\n\t" "s_mov_b64 exec, 1\n\t" "ds_write_b64 v116, %[t]\n\t" \
-                     "ds_write_b64 v116, %[g0] offset:8\n\t" "ds_write_b32 v116, v117 offset:32\n\t"
-__device__ __forceinline__ void agc_tight_run(double &g0, const double keep, const double add, double &rmax, int &j, const int jend,
-                                              const int gensh, const int taghi, const unsigned a_gv0, const unsigned a_rec0,
-                                              const unsigned a_gv_spare, const unsigned a_rec_spare, const unsigned a_wstat,
-                                              const unsigned a_tmax)
+// The runner's tight loop -- `count` whole PLAIN tiles (no clip, no window boundary, room in the ring for all of them) -- as one
+// block of assembly.  What bounds it: a lone wave is given ONE issue slot every four cycles whatever the instruction
+// (profiles/ub/agc_chain_shadow.hip: every instruction added to the chain, scalar ones between two dependent FP64 operations
+// included, costs 4.0 cycles; nothing rides in a shadow), so the loop is a count of instructions and is written as one.
+//   - The recurrence without a shift of EXEC per step: lane L must make L steps, L = b5..b0, so the lanes with bit 5 set make
+//     32 steps under one mask, then those with bit 4 set 16 steps, ... 1 step: every lane applies the same operation to its own
+//     running value L times in a row, which is the sample-by-sample sequence G_0 .. G_L bit for bit, in 63 x 2 + 6 slots
+//     instead of 63 x 3.
+//   - A tile's hand-over is deferred to the head of the next tile's pass (its end gain is lane 0 of the next chain register,
+//     which no mask ever touches): one 8-byte store of the gains, then from lane 0 one 16-byte store {end, step constant} and
+//     the tag -- the tag last.  The two chain registers alternate and each is followed by a copy of the step constant, so that
+//     {end, step} is one register quadruple.  The first pass hands over to a spare slot nobody reads.
+//   - Ring slots are 1 KiB apart in a 16 KiB-aligned ring: slot address = (running tile count << 10 & mask) | lane base.
+//   - No ring test inside: the caller looks at the walker's progress and asks for no more tiles than there is room for.
+// Wait states of the gfx940 family (VALU-written VGPR -> v_readlane: 1; VALU-written SGPR -> VALU operand: 2) are kept by the
+// order of the instructions.  v112-v131, s44-s45 and s[60:71] are the block's own (clobbers).
+#define AGC_B1(X) "v_mul_f64 " X ", " X ", %[k]\n\t" "v_add_f64 " X ", " X ", %[t]\n\t"
+#define AGC_B2(X) AGC_B1(X) AGC_B1(X)
+#define AGC_B4(X) AGC_B2(X) AGC_B2(X)
+#define AGC_B8(X) AGC_B4(X) AGC_B4(X)
+#define AGC_B16(X) AGC_B8(X) AGC_B8(X)
+#define AGC_B32(X) AGC_B16(X) AGC_B16(X)
+#define AGC_BIN(X) "s_mov_b64 exec, s[60:61]\n\t" AGC_B32(X) "s_mov_b64 exec, s[62:63]\n\t" AGC_B16(X) "s_mov_b64 exec, s[64:65]\n\t" AGC_B8(X) \
+                   "s_mov_b64 exec, s[66:67]\n\t" AGC_B4(X) "s_mov_b64 exec, s[68:69]\n\t" AGC_B2(X) "s_mov_b64 exec, s[70:71]\n\t" AGC_B1(X) \
+                   "s_mov_b64 exec, -1\n\t"
+#define AGC_MASKS "s_mov_b32 s60, 0\n\t" "s_mov_b32 s61, -1\n\t" "s_mov_b32 s62, 0xffff0000\n\t" "s_mov_b32 s63, 0xffff0000\n\t" \
+                  "s_mov_b32 s64, 0xff00ff00\n\t" "s_mov_b32 s65, 0xff00ff00\n\t" "s_mov_b32 s66, 0xf0f0f0f0\n\t" "s_mov_b32 s67, 0xf0f0f0f0\n\t" \
+                  "s_mov_b32 s68, 0xcccccccc\n\t" "s_mov_b32 s69, 0xcccccccc\n\t" "s_mov_b32 s70, 0xaaaaaaaa\n\t" "s_mov_b32 s71, 0xaaaaaaaa\n\t"
+// hand-over of the tile whose gains are in Y; X (with the step constant behind it: XQ) is the chain register of the tile after it
+#define AGC_HAND(XQ, Y) "ds_write_b64 v115, " Y "\n\t" "s_mov_b64 exec, 1\n\t" "ds_write_b128 v115, " XQ " offset:512\n\t" \
+                        "ds_write_b32 v115, v117 offset:544\n\t"
+// one tile: chain in X (low / high register XL / XH), the tile before it (gains in Y) handed over, the next tile's first gain into Y
+#define AGC_TILE(X, XQ, XL, XH, Y) \
+        "ds_read_b64 v[112:113], v118\n\t" AGC_HAND(XQ, Y) AGC_BIN(X) \
+        "v_readlane_b32 s44, v" XL ", 63\n\t" "v_readlane_b32 s45, v" XH ", 63\n\t" \
+        "v_add_u32 v119, 0x400, v119\n\t" "v_and_or_b32 v115, v119, v120, v121\n\t" \
+        "v_mul_f64 " Y ", %[k], s[44:45]\n\t" "v_add_f64 " Y ", " Y ", %[t]\n\t" \
+        "v_add_u32 v117, 1, v117\n\t" "v_add_u32 v118, 8, v118\n\t" "s_waitcnt lgkmcnt(0)\n\t" "v_max_f64 %[rm], %[rm], v[112:113]\n\t"
+__device__ __forceinline__ void agc_tight_run(double &g0, const double keep, const double add, double &rmax, const int count, const int j,
+                                              const int tag_j, const unsigned a_ring_lane, const unsigned a_spare_lane, const unsigned a_tmax)
 {
+    int left = count - 1;                   // tiles behind the one in hand
     asm volatile(
-        "v_mov_b32 v115, %[agvs]\n\t" "v_mov_b32 v116, %[arecs]\n\t" "v_mov_b32 v117, -1\n\t" "v_mov_b32 v118, %[atm]\n\t"
-        "v_mov_b64 v[110:111], %[g0]\n\t"
+        AGC_MASKS
+        "v_mov_b64 v[124:125], %[g0]\n\t" "v_mov_b64 v[128:129], %[g0]\n\t" "v_mov_b64 v[126:127], %[t]\n\t" "v_mov_b64 v[130:131], %[t]\n\t"
+        "v_mov_b32 v115, %[aspare]\n\t" "v_mov_b32 v117, %[tagm1]\n\t" "v_mov_b32 v118, %[atm]\n\t" "v_mov_b32 v119, %[jm1]\n\t"
+        "v_mov_b32 v120, 0x3c00\n\t" "v_mov_b32 v121, %[aring]\n\t"
         "1:\n\t"
-        "ds_read_b32 v114, %[aw]\n\t"
-        "ds_read_b64 v[112:113], v118\n\t"
-        AGC_HANDOVER
-        "s_mov_b64 exec, -1\n\t"
-        "v_mov_b64 v[108:109], %[g0]\n\t"
-        "s_mov_b64 exec, -2\n\t"
-        "v_mul_f64 v[108:109], v[108:109], %[k]\n\t" "v_add_f64 v[108:109], v[108:109], %[t]\n\t"
-        AGC_T1 AGC_T1
-        "s_and_b32 s46, %[j], %[ringm1]\n\t"
-        AGC_T1
-        "s_lshl_b32 s48, s46, 9\n\t"
-        AGC_T1
-        "s_mul_i32 s49, s46, 48\n\t"
-        AGC_T1
-        "s_add_i32 s49, s49, %[arec0]\n\t"
-        AGC_T1
-        "s_or_b32 s50, %[taghi], %[j]\n\t"
-        AGC_T1
-        "s_add_i32 s51, %[j], %[gensh]\n\t"
-        AGC_T1 AGC_T4 AGC_T16 AGC_T16 AGC_T16 AGC_T1 AGC_T1
-        "s_mov_b64 exec, -1\n\t"
-        "s_nop 1\n\t"
-        "v_readlane_b32 s44, v108, 63\n\t"
-        "v_readlane_b32 s45, v109, 63\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_readfirstlane_b32 s46, v114\n\t"
-        "s_nop 0\n\t"
-        "v_mul_f64 v[122:123], %[k], s[44:45]\n\t"
-        "s_sub_i32 s51, s51, s46\n\t"
-        "s_cmp_gt_u32 s51, %[ringm1]\n\t"
-        "v_add_f64 v[122:123], v[122:123], %[t]\n\t"
-        "s_cbranch_scc1 3f\n\t"
-        "v_max_f64 %[rm], %[rm], v[112:113]\n\t"
-        "v_mov_b64 v[110:111], v[108:109]\n\t"
-        "v_add_u32 v115, s48, %[agv0]\n\t"
-        "v_mov_b32 v116, s49\n\t"
-        "v_mov_b32 v117, s50\n\t"
-        "v_add_u32 v118, 8, v118\n\t"
-        "v_mov_b64 %[g0], v[122:123]\n\t"
-        "s_add_i32 %[j], %[j], 1\n\t"
-        "s_cmp_lt_i32 %[j], %[jend]\n\t"
-        "s_cbranch_scc1 1b\n\t"
+        AGC_TILE("v[124:125]", "v[124:127]", "124", "125", "v[128:129]")
+        "s_add_u32 %[left], %[left], -1\n\t" "s_cbranch_scc0 2f\n\t"
+        AGC_TILE("v[128:129]", "v[128:131]", "128", "129", "v[124:125]")
+        "s_add_u32 %[left], %[left], -1\n\t" "s_cbranch_scc1 1b\n\t"
+        // left behind an even number of tiles: the last one's gains are in 128:129, the gain after it in 124:125
+        AGC_HAND("v[124:127]", "v[128:129]") "s_mov_b64 exec, -1\n\t" "v_mov_b64 %[g0], v[124:125]\n\t" "s_branch 3f\n\t"
+        "2:\n\t"
+        AGC_HAND("v[128:131]", "v[124:125]") "s_mov_b64 exec, -1\n\t" "v_mov_b64 %[g0], v[128:129]\n\t"
         "3:\n\t"
-        AGC_HANDOVER
-        "s_mov_b64 exec, -1\n\t"
-        : [g0] "+v"(g0), [rm] "+v"(rmax), [j] "+s"(j)
-        : [k] "v"(keep), [t] "v"(add), [jend] "s"(jend), [gensh] "s"(gensh), [taghi] "s"(taghi), [agv0] "v"(a_gv0), [arec0] "s"(a_rec0),
-          [agvs] "v"(a_gv_spare), [arecs] "v"(a_rec_spare), [aw] "v"(a_wstat), [atm] "v"(a_tmax), [ringm1] "n"(AGC_RING - 1)
-        : "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v122", "v123",
-          "s44", "s45", "s46", "s48", "s49", "s50", "s51", "scc", "memory");
+        : [g0] "+v"(g0), [rm] "+v"(rmax), [left] "+s"(left)
+        : [k] "v"(keep), [t] "v"(add), [aring] "v"(a_ring_lane), [aspare] "v"(a_spare_lane), [atm] "v"(a_tmax),
+          [tagm1] "v"(tag_j - 1), [jm1] "v"((j - 1) << 10)
+        : "v112", "v113", "v115", "v117", "v118", "v119", "v120", "v121", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131",
+          "s44", "s45", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "scc", "memory");
+}
+// a whole chain from lane 0 (start = 0) by the same masks, for the tiles made outside the tight loop
+__device__ __forceinline__ double agc_chain_bin(const double g0, const double keep, const double add)
+{
+    double gv = g0;
+    asm volatile(AGC_MASKS
+                 "s_mov_b64 exec, s[60:61]\n\t" AGC_B32("%[g]") "s_mov_b64 exec, s[62:63]\n\t" AGC_B16("%[g]") "s_mov_b64 exec, s[64:65]\n\t" AGC_B8("%[g]")
+                 "s_mov_b64 exec, s[66:67]\n\t" AGC_B4("%[g]") "s_mov_b64 exec, s[68:69]\n\t" AGC_B2("%[g]") "s_mov_b64 exec, s[70:71]\n\t" AGC_B1("%[g]")
+                 "s_mov_b64 exec, -1\n\t"
+                 : [g] "+v"(gv) : [k] "v"(keep), [t] "v"(add)
+                 : "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "scc");
+    return gv;
 }
 
 __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
 {
 #pragma clang fp contract(off)
-    __shared__ double sp_gv[AGC_RING + 1][64];      // runner -> walker: the gains of tile k in slot k % AGC_RING (one spare row
-    __shared__ AgcSlot sp_rec[AGC_RING + 1];        // nobody reads); what it assumed and what it ends with, and the tag that says so
+    // runner -> walker: the gains of tile k, what the runner assumed and what it ends with, and the tag that says so, in slot
+    // k % AGC_RING (one spare slot nobody reads)
+    __shared__ __attribute__((aligned(16384))) AgcRingSlot ring[AGC_RING + 1];
     __shared__ double tmaxs[2][AGC_CHUNK];          // fetcher -> runner: max |x| over each tile of the chunk
-    static_assert(sizeof(AgcSlot) == 48 && offsetof(AgcSlot, end) == 8 && offsetof(AgcSlot, tag) == 32, "agc_tight_run writes these offsets");
+    static_assert(sizeof(AgcRingSlot) == 1024 && AGC_RING == 16 && offsetof(AgcRingSlot, rec) == 512 && offsetof(AgcSlot, end) == 0 && offsetof(AgcSlot, add) == 8 &&
+                  offsetof(AgcSlot, tag) == 32, "agc_tight_run writes these offsets");
     __shared__ int wstat;                           // walker -> runner, fetcher: restart generation << 20 | tiles finished
     __shared__ int fetched;                         // fetcher -> walker: chunks in LDS
     __shared__ double rs_g, rs_add, rs_max;         // walker -> runner, with a new generation: the true state at sample
@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
     const int cl = a.cls[rx];
     const int n_new = a.n_c[cl];
     if (!a.started[rx] || n_new <= 0) return;       // (the whole workgroup)
-    if (threadIdx.x < AGC_RING) sp_rec[threadIdx.x].tag = -1;
+    if (threadIdx.x < AGC_RING) ring[threadIdx.x].rec.tag = -1;
     if (threadIdx.x == 0) { wstat = 0; fetched = 0; aborted = 0; }
     __syncthreads();
     __builtin_amdgcn_s_setprio(3);      // latency-bound waves among the front end's throughput-bound ones: issue first
@@ -1534,12 +1534,12 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
             const int slot = jj & (AGC_RING - 1);
             // The tag goes last and nothing waits in between: the LDS executes one wave's instructions in the order
             // they were issued, so whoever sees the tag sees the tile.  (The compiler is told not to reorder them.)
-            sp_gv[slot][lane] = gs;
+            ring[slot].gv[lane] = gs;
             if (lane == 0) {
-                sp_rec[slot].add = a0; sp_rec[slot].end = pend;
-                if (!plain) { sp_rec[slot].add1 = a1; sp_rec[slot].bl = bl; sp_rec[slot].clip = cl_; }
+                ring[slot].rec.add = a0; ring[slot].rec.end = pend;
+                if (!plain) { ring[slot].rec.add1 = a1; ring[slot].rec.bl = bl; ring[slot].rec.clip = cl_; }
                 asm volatile("" ::: "memory");
-                poke(&sp_rec[slot].tag, tag_of(gen, jj) | (plain ? (int)0x80000000 : 0));
+                poke(&ring[slot].rec.tag, tag_of(gen, jj) | (plain ? (int)0x80000000 : 0));
             }
         };
         while (alive) {
@@ -1555,15 +1555,23 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                 if (T < jend) jend = T;
                 if (j + (ahead >> 6) < jend) jend = j + (ahead >> 6);
                 const int j0 = j;
+                bool room_out = false;              // the ring, not jend, cut the run short
                 if (j < jend) {
-                    AGC_PROBE(0);
-                    j = uni(j);
-                    agc_tight_run(g0, c.keep, add, rmax, j, uni(jend), uni(gen << 20), uni((int)(tag_of(gen, 0) | 0x80000000)), lds_addr(&sp_gv[0][lane]),
-                                  (unsigned)uni((int)lds_addr(&sp_rec[0])), lds_addr(&sp_gv[AGC_RING][lane]), lds_addr(&sp_rec[AGC_RING]), lds_addr(&wstat),
-                                  lds_addr(&tmaxs[(j / AGC_CHUNK) & 1][j % AGC_CHUNK]));
-                    AGC_PROBE(1);
+                    // as many tiles as the ring has room for (the walker's progress, looked at once per run; a restart shows
+                    // as another generation and sends the run to the general step)
+                    const int ws = uni(peek(&wstat));
+                    int room = (ws >> 20) == (gen & 0x7ff) ? AGC_RING - (j - (ws & 0xfffff)) : 0;
+                    int count = jend - j;
+                    if (room < count) { count = room; room_out = true; }
+                    if (count > 0) {
+                        AGC_PROBE(0);
+                        agc_tight_run(g0, c.keep, add, rmax, uni(count), uni(j), uni((int)(tag_of(gen, j) | 0x80000000)), lds_addr(&ring[0].gv[lane]),
+                                      lds_addr(&ring[AGC_RING].gv[lane]), lds_addr(&tmaxs[(j / AGC_CHUNK) & 1][j % AGC_CHUNK]));
+                        j += count;
+                        AGC_PROBE(1);
+                    }
                 }
-                const bool ran_out = j >= jend;     // (not: left early for the general step)
+                const bool ran_out = j >= jend && !room_out;     // (not: left early for the general step)
                 ir += (j - j0) << 6;
                 while (ir >= a.buf_size) ir -= a.buf_size;
                 if (j < T && j / AGC_CHUNK >= f_known) f_known = uni(peek(&fetched));
@@ -1581,7 +1589,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                         const int bl = left;
                         const int ws_v = peek(&wstat);
                         const double mv = sm[(j / AGC_CHUNK) & 1][(j % AGC_CHUNK) * 64 + lane];
-                        double gs = agc_chain<true>(g0, c.keep, add, 0);       // (right up to lane bl; the lanes behind are made again)
+                        double gs = agc_chain_bin(g0, c.keep, add);             // (right up to lane bl; the lanes behind are made again)
                         double nmax = walk_max(rmax, mv, lane < bl);
                         const double clip_gain = c.ceil_ / nmax;
                         const double tnew = c.fm ? clip_gain : (c.rel > clip_gain ? clip_gain : c.rel);
@@ -1679,7 +1687,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
         auto acquire = [&](const int k) {
             const int slot = k & (AGC_RING - 1);
             const int want = tag_of(gen, k);
-            const unsigned a_rec = lds_addr(&sp_rec[slot]), a_gv = lds_addr(&sp_gv[slot][lane]);
+            const unsigned a_rec = lds_addr(&ring[slot].rec), a_gv = lds_addr(&ring[slot].gv[lane]);
             const unsigned a_mv = lds_addr(&sm[(k / AGC_CHUNK) & 1][(k % AGC_CHUNK) * 64 + lane]);
             int spins = 0, tagv;
             qk_d2 r0; qk_i4 r1;
@@ -1704,7 +1712,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
 #endif
             // (what an asm block returns is per-lane to the compiler: the record's fields are made wave-uniform again, or every
             // test on them turns into EXEC-mask bookkeeping)
-            sa = unid(r0.x); se = unid(r0.y);
+            se = unid(r0.x); sa = unid(r0.y);
             sa1 = sa; sb = 64; sc = 0;              // a plain tile
             if (tag >= 0) { sa1 = __hiloint2double(uni(r1.y), uni(r1.x)); sb = uni(r1.z); sc = uni(r1.w); }
         };
@@ -1821,10 +1829,10 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                     if (k / AGC_CHUNK >= f_seen) { f_seen = uni(peek(&fetched)); if (k / AGC_CHUNK >= f_seen) break; }
                     const int slot = k & (AGC_RING - 1);
                     int tagv; qk_d2 r0; qk_i4 r1; double gvv, mv;
-                    agc_take(lds_addr(&sp_rec[slot]), lds_addr(&sp_gv[slot][lane]),
+                    agc_take(lds_addr(&ring[slot].rec), lds_addr(&ring[slot].gv[lane]),
                              lds_addr(&sm[(k / AGC_CHUNK) & 1][(k % AGC_CHUNK) * 64 + lane]), tagv, r0, r1, gvv, mv);
                     if (uni(tagv) != (int)(tag_of(gen, k) | 0x80000000)) break;         // not there yet, or not a plain tile
-                    const bool quiet = (unid(r0.x) == cur_add) & (readlane_f64(gvv, 0) == s.gain) & !(mv * gvv > c.ceil_);
+                    const bool quiet = (unid(r0.y) == cur_add) & (readlane_f64(gvv, 0) == s.gain) & !(mv * gvv > c.ceil_);
                     if (__ballot(quiet) != ~0ull) break;
                     unsigned long long over = __ballot(mv > s.themax);
                     while (over) {
@@ -1834,7 +1842,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                     s.pad++;
                     s.index_read += 64;
                     if (s.index_read >= a.buf_size) s.index_read -= a.buf_size;
-                    s.gain = unid(r0.y);
+                    s.gain = unid(r0.x);
                     g[(k << 6) + lane] = gvv;
                     ++k;
                     lds_store_lane0(lds_addr(&wstat), tag_of(gen, k));
