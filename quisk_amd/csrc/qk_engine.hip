@@ -164,7 +164,7 @@ struct qk_engine {
     int fe_share = 100;        // percent of the resident slots the front end may occupy (QK_FE_SHARE)
     int fe_rounds = 2;         // front-end workgroups launched per resident slot (QK_FE_ROUNDS)
     bool fuse_chains = true;   // short blocks: a class chain as one launch (k_chain_fused; QK_FUSE=0 keeps the separate kernels)
-    int fuse_max_in = 4096;    // ... up to this many samples per receiver behind the decimators (QK_FUSE_MAX)
+    int fuse_max_in = 4096;    // ... up to this many samples behind the decimators, all receivers of the chain together (QK_FUSE_MAX)
     bool fe_packed = true;     // fp32 mode: the packed-FP32 front end k_frontend_pk (QK_FE_PACKED=0: the plane-per-lane float form)
     int rate_case = 0;
     // input
@@ -1624,9 +1624,11 @@ static int measure_freq_block(qk_engine *e, const Stream &dec)
 // run one chain over `nlist` receivers; `input` is the stream feeding stage.in == -1
 // May this run of a chain go out as one launch (k_chain_fused)?  Short blocks only (one workgroup per receiver does all the
 // work), chains made of the stage kinds the kernel knows, and none of the audio hooks that are kernels of their own.
-static bool chain_fusable(const qk_engine *e, const Chain &c, const Stream &input)
+static bool chain_fusable(const qk_engine *e, const Chain &c, const Stream &input, int nlist)
 {
-    if (!e->fuse_chains || &c == &e->front || input.n <= 0 || input.n > e->fuse_max_in) return false;
+    // (one workgroup per receiver: worth it only while the whole launch is a few thousand samples -- with 128 receivers of
+    // 819 samples each the separate, wider kernels are twice as fast)
+    if (!e->fuse_chains || &c == &e->front || input.n <= 0 || (long long)input.n * std::max(1, nlist) > e->fuse_max_in) return false;
     if ((int)c.stages.size() + 2 > QK_FUSED_MAX) return false;
     for (const auto &st : c.stages) {
         if (st.kind == ST_RESAMP || st.in_after || st.out_after) return false;
@@ -1642,7 +1644,7 @@ static bool chain_fusable(const qk_engine *e, const Chain &c, const Stream &inpu
 
 static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_list, int nlist, hipStream_t cs)
 {
-    const bool fuse = chain_fusable(e, c, input);
+    const bool fuse = chain_fusable(e, c, input, nlist);
     FusedArgs fz{};
     Chain::FracSlot *frac_slot_used = nullptr;
     double ma_close = 0;
