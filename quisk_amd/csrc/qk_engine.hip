@@ -163,7 +163,9 @@ struct qk_engine {
     int fe_slots = 2304;       // resident one-wave workgroups of k_frontend_wave on the whole chip (occupancy query)
     int fe_share = 100;        // percent of the resident slots the front end may occupy (QK_FE_SHARE)
     int fe_rounds = 2;         // front-end workgroups launched per resident slot (QK_FE_ROUNDS)
-    bool fuse_chains = true;   // short blocks: a class chain as one launch (k_chain_fused; QK_FUSE=0 keeps the separate kernels)
+    bool fuse_chains = false;  // short blocks: a class chain as one launch (k_chain_fused, QK_FUSE=1).  Off: measured at config 1 it saves
+                               // 26 us of host enqueue per block and costs 36 us of GPU time (one workgroup runs what the separate
+                               // kernels spread over several): 160 against 150 us per block
     int fuse_max_in = 4096;    // ... up to this many samples behind the decimators, all receivers of the chain together (QK_FUSE_MAX)
     bool fe_packed = true;     // fp32 mode: the packed-FP32 front end k_frontend_pk (QK_FE_PACKED=0: the plane-per-lane float form)
     int rate_case = 0;
@@ -2069,6 +2071,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             span = (span + unit - 1) / unit * unit;
             const int nspans = (int)((consumed + span - 1) / span);
             fa.span_len = (int)span; fa.nspans = nspans;
+            fa.hist_out = e->d_mixhist[e->pp ^ 1]; fa.v0_next = e->d_v0[e->pp ^ 1];
             switch (S) {
             case 1: launch_frontend<1>(e, fa, nspans); break;
             case 2: launch_frontend<2>(e, fa, nspans); break;
@@ -2078,21 +2081,22 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             }
         }
     }
-    if (S > 0)
-        hipLaunchKernelGGL(k_mixhist_update, dim3((e->H + 255) / 256, e->nrx), dim3(256), 0, e->fe_stream, fa,
+    if (!fa.hist_out) {
+        // (no front-end launch in this block, or the mixer alone: the history and the tune vector move on by a launch of their own)
+        hipLaunchKernelGGL(k_mixhist_update, dim3(S > 0 ? (e->H + 255) / 256 : 1, e->nrx), dim3(256), 0, e->fe_stream, fa,
                            e->d_mixhist[e->pp ^ 1], e->d_v0[e->pp ^ 1]);
-    else
-        hipLaunchKernelGGL(k_mixhist_update, dim3(1, e->nrx), dim3(256), 0, e->fe_stream, fa,
-                           e->d_mixhist[e->pp ^ 1], e->d_v0[e->pp ^ 1]);
+    }
     e->pp ^= 1;
     e->N0 += n;
     if (fe_writes) {
-        // head copy: the last `hist` samples of the previous block (in the twin) go in front of this one
+        // head copy: the last `hist` samples of the previous block (in the twin) go in front of this one.  On the main stream,
+        // beside the front end: what it reads the previous block's front end wrote (the main stream waited for it then), what
+        // it writes lies in front of the front end's first output and was last read by the chains of the block before last
         Stream &f0 = F.streams[0];
         TailArgs th{}; th.count = 1; th.rx_list = nullptr;
         th.t[0] = TailDesc{F.front_alt, f0.rx_stride(), f0.hist + f0.cap, f0.planes, f0.hist, F.front_last_n, f0.d};
         if (f0.hist > 0 && F.front_last_n > 0)
-            hipLaunchKernelGGL(k_save_tails, dim3(1, 2, e->nrx), dim3(256), 0, e->fe_stream, th);
+            hipLaunchKernelGGL(k_save_tails, dim3(1, 2, e->nrx), dim3(256), 0, e->stream, th);
         F.front_last_n = f0.n;
     }
     {

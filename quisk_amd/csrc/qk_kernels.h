@@ -105,6 +105,8 @@ struct FrontArgs {
     long long g_lo0, g_end;    // global input range [g_lo0, g_end) consumed by this block's outputs (multiples of 2^S)
     int span_len;              // input samples per span (multiple of 2^S)
     int nspans;                // spans per receiver; a workgroup walks spans blockIdx.x, blockIdx.x + gridDim.x, ...
+    double2 *hist_out;         // the front-end kernels also leave the next block's history and tune vector (what k_mixhist_update
+    double2 *v0_next;          // does; null: a launch of that kernel follows)
 };
 
 // Mixer alone (no half-band in front of the FIR chain: rates < 96 ksps).
@@ -121,11 +123,10 @@ __global__ __launch_bounds__(256) void k_mix_only(FrontArgs a)
 
 // After a block: the last H mixed samples become the next block's history, and the tune vector moves on
 // by phase^n.  hist_in/hist_out and v0/v0_next are ping-pong pairs.
-__global__ __launch_bounds__(256) void k_mixhist_update(FrontArgs a, double2 *hist_out, double2 *v0_next)
+__device__ __forceinline__ void mixhist_update(const FrontArgs &a, double2 *hist_out, double2 *v0_next, const int rx, const int first, const int stride)
 {
-    const int rx = blockIdx.y;
     const int on = a.mt.mix_on[rx];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.H; i += gridDim.x * 256) {
+    for (int i = first; i < a.H; i += stride) {
         long long k = (long long)a.n - a.H + i;           // block-relative index
         double2 v;
         if (k >= 0) {
@@ -136,8 +137,12 @@ __global__ __launch_bounds__(256) void k_mixhist_update(FrontArgs a, double2 *hi
         }
         hist_out[(long long)rx * a.H + i] = v;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
+    if (first == 0)
         v0_next[rx] = on ? mix_w(a.mt, rx, a.n) : a.mt.v0[rx];
+}
+__global__ __launch_bounds__(256) void k_mixhist_update(FrontArgs a, double2 *hist_out, double2 *v0_next)
+{
+    mixhist_update(a, hist_out, v0_next, blockIdx.y, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -402,6 +407,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FE_WAVES_PER
     constexpr int W = FwLayout::warm(S);
     constexpr int NIT = FW_CHUNK / 64;
     const int mix = a.mt.mix_on[rx];
+    // the next block's history (its own buffer: nobody reads it in this launch), a sample or two per lane across the grid
+    if (a.hist_out) mixhist_update(a, a.hist_out, a.v0_next, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
     const double2 *histp = a.hist + (long long)rx * a.H;
     double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
     const long long dummy = (long long)a.out.plane_stride - a.out.hist - 1;     // last slot of the plane: never a sample
@@ -672,6 +679,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WAVES_PER
     constexpr int W = FwLayout::warm(S);
     constexpr int NIT = PK_CHUNK / 64;
     const int mix = a.mt.mix_on[rx];
+    // the next block's history (its own buffer: nobody reads it in this launch), a sample or two per lane across the grid
+    if (a.hist_out) mixhist_update(a, a.hist_out, a.v0_next, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
     const double2 *histp = a.hist + (long long)rx * a.H;
     double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
     const long long dummy = (long long)a.out.plane_stride - a.out.hist - 1;     // last slot of the plane: never a sample

@@ -312,3 +312,27 @@ def test_three_fifths_and_the_resampler(fs, sizes):
     pr.close(); own.close()
     pr.check()
     assert differs
+
+
+@pytest.mark.parametrize("fs,blk,mode,play", [(192000, 960, 3, 48000), (250000, 5000, 5, 96000), (1536000, 16384, 4, 48000)])
+def test_fused_chain_is_the_separate_kernels(fs, blk, mode, play, monkeypatch):
+    """QK_FUSE=1 (a short block's class chain as one launch, k_chain_fused; off by default) makes the
+    audio of the separate kernels bit for bit: same arithmetic, same order, one workgroup per receiver."""
+    import os
+    from quisk_amd import Engine, rx_filter
+    from quisk_amd.synth import make_iq
+    x = make_iq(blk * 12, fs, [fs // 10], [mode], 77)
+    outs = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("QK_FUSE", fuse)
+        eng = Engine(fs, n_receivers=1, max_block=blk, playback_rate=play)
+        fi, fq, bw, off = rx_filter(fs, mode)
+        eng.set_mode(0, mode); eng.set_tune(0, fs // 10); eng.set_filters(0, fi, fq, bw, off)
+        got = []
+        for i in range(12):
+            eng.process(x[i * blk:(i + 1) * blk])
+            got.append(eng.audio(0))
+        eng.close()
+        outs.append(np.concatenate(got))
+    assert outs[0].size == outs[1].size and outs[0].size > 0
+    assert np.array_equal(outs[0].view(np.float64).view(np.uint64), outs[1].view(np.float64).view(np.uint64))
