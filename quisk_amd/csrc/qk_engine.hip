@@ -72,6 +72,8 @@ enum ObjId { OB_NONE = -1, OB_HB5 = 0, OB_HB4, OB_D48, OB_CRX, OB_DRX, OB_HB6, O
 struct Stream {
     double *d = nullptr;
     int planes = 1, hist = 0, cap = 0, n = 0;
+    bool f32 = false;          // the elements are floats (same element strides on the same allocation): the fp32 mode's front-chain
+                               // streams between the packed front end and the float FIRs
     long long rx_stride() const { return (long long)planes * (hist + cap); }
     StreamView view() const { return StreamView{d, rx_stride(), hist + cap, hist}; }
 };
@@ -881,6 +883,26 @@ static FirTab push_fir(DevTables &t, const double *src, int n, int D)
 
 static int init_spectrum(qk_engine *e);
 
+// fp32 mode: the front chain's streams that only float kernels touch hold floats -- the packed front end's output and what
+// lies between two float FIRs (at 61.44 Msps the /3 stage reads 134 MB per block instead of 268).  Not the decimated stream
+// the classes read, not a stream two stages share, not behind the mixer-only front end (QK_F32_STREAMS=0: all double).
+static void mark_float_streams(qk_engine *e)
+{
+    Chain &c = e->front;
+    if (const char *v = getenv("QK_F32_STREAMS")) if (!atoi(v)) return;
+    if (!e->fp32 || !e->fe_packed || e->S < 1) return;
+    for (int s = 0; s < (int)c.streams.size(); s++) {
+        if (s == c.aud || s == c.shared) continue;
+        bool ok = true, read = false;
+        for (const auto &st : c.stages) {
+            if (st.out == s && !(st.kind == ST_FIR && st.hf && !st.out_after)) ok = false;
+            if (st.in == s) { read = true; if (!(st.kind == ST_FIR && st.hf && !st.in_after)) ok = false; }
+            if (s == 0 && st.in < 0) { read = true; if (!(st.kind == ST_FIR && st.hf && !st.in_after)) ok = false; }
+        }
+        c.streams[s].f32 = ok && read;
+    }
+}
+
 static int init_receivers(qk_engine *e)
 {
     const qk_config &cfg = e->cfg;
@@ -893,6 +915,7 @@ static int init_receivers(qk_engine *e)
     if (const char *v = getenv("QK_FE_PACKED")) e->fe_packed = atoi(v) != 0;
     if (const char *v = getenv("QK_FUSE")) e->fuse_chains = atoi(v) != 0;
     if (const char *v = getenv("QK_FUSE_MAX")) e->fuse_max_in = std::max(1, atoi(v));
+    mark_float_streams(e);
     {
         int per_cu = 0, cus = 256;
         hipDeviceProp_t prop;
@@ -1675,7 +1698,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
                 f.D = st.D; f.TQP = st.TQP; f.first = first;
             } else if (n_out > 0) {
                 const bool f32 = e->fp32 && st.hf;
-                FirTArgs a{in_v, out_v, f32 ? (const void *)st.hf : (const void *)st.h, st.TQP, first, n_out, d_list};
+                FirTArgs a{in_v, out_v, f32 ? (const void *)st.hf : (const void *)st.h, st.TQP, first, n_out, d_list, in.f32 ? 1 : 0, out.f32 ? 1 : 0};
                 Timer tm(e, st.timer, cs);
                 // outputs per lane: 5 (an LDS load feeds 3.3 FMAs), 3 for the /5 stage: its five-branch tile left room for five
                 // workgroups per CU only (10 % faster).  /2 alone gains 7 % from the smaller tile too, but its extra workgroups
@@ -1870,7 +1893,7 @@ static void add_tails(TailArgs &ta, Chain &c, int skip)
         Stream &s = c.streams[i];
         if (i == skip || s.hist <= 0 || s.n <= 0) continue;
         if (ta.count >= QK_MAX_TAILS) break;
-        ta.t[ta.count++] = TailDesc{s.d, s.rx_stride(), s.hist + s.cap, s.planes, s.hist, s.n, s.d};
+        ta.t[ta.count++] = TailDesc{s.d, s.rx_stride(), s.hist + s.cap, s.planes, s.hist, s.n, s.d, s.f32 ? 1 : 0};
     }
 }
 
@@ -2056,6 +2079,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         if (e->read_pending[q]) HIPCHECK(hipStreamWaitEvent(e->fe_stream, e->ev_read[q], 0));
     }
     fa.out = F.streams[0].view();
+    fa.out_f32 = F.streams[0].f32 ? 1 : 0;
     {
         Timer tm(e, QK_KT_FRONTEND, e->fe_stream);
         if (S == 0) {
@@ -2094,7 +2118,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         // it writes lies in front of the front end's first output and was last read by the chains of the block before last
         Stream &f0 = F.streams[0];
         TailArgs th{}; th.count = 1; th.rx_list = nullptr;
-        th.t[0] = TailDesc{F.front_alt, f0.rx_stride(), f0.hist + f0.cap, f0.planes, f0.hist, F.front_last_n, f0.d};
+        th.t[0] = TailDesc{F.front_alt, f0.rx_stride(), f0.hist + f0.cap, f0.planes, f0.hist, F.front_last_n, f0.d, f0.f32 ? 1 : 0};
         if (f0.hist > 0 && F.front_last_n > 0)
             hipLaunchKernelGGL(k_save_tails, dim3(1, 2, e->nrx), dim3(256), 0, e->stream, th);
         F.front_last_n = f0.n;
@@ -3445,6 +3469,15 @@ int qk_debug_tap(qk_engine *e, int which, int rx, double *out, int cap)
     if (!s || !s->d) return fail(QK_EINVAL, "no such tap");
     SYNC_ALL(e);
     const int m = std::min(s->n, cap);
+    if (s->f32) {      // a float stream: widened on the host
+        std::vector<float> tmp((size_t)std::max(m, 1));
+        for (int p = 0; p < s->planes && m > 0; p++) {
+            HIPCHECK(hipMemcpy(tmp.data(), reinterpret_cast<const float *>(s->d) + (long long)rx * s->rx_stride() + (long long)p * (s->hist + s->cap) + s->hist,
+                               sizeof(float) * m, hipMemcpyDeviceToHost));
+            for (int i = 0; i < m; i++) out[(size_t)p * cap + i] = (double)tmp[i];
+        }
+        return m;
+    }
     for (int p = 0; p < s->planes && m > 0; p++)
         HIPCHECK(hipMemcpy(out + (size_t)p * cap, s->d + (long long)rx * s->rx_stride() + (long long)p * (s->hist + s->cap) + s->hist,
                            sizeof(double) * m, hipMemcpyDeviceToHost));

@@ -27,6 +27,13 @@ __device__ __forceinline__ double *sv_ptr(const StreamView &s, int rx, int plane
     return s.d + (long long)rx * s.rx_stride + (long long)plane * s.plane_stride + s.hist;
 }
 
+// a stream whose elements are X (float in the fp32 mode's front chain): the same element indices on the same allocation
+template <class X>
+__device__ __forceinline__ X *sv_ptr_t(const StreamView &s, int rx, int plane)
+{
+    return reinterpret_cast<X *>(s.d) + (long long)rx * s.rx_stride + (long long)plane * s.plane_stride + s.hist;
+}
+
 __device__ __forceinline__ double2 cmul(double2 a, double2 b)
 {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -107,6 +114,7 @@ struct FrontArgs {
     int nspans;                // spans per receiver; a workgroup walks spans blockIdx.x, blockIdx.x + gridDim.x, ...
     double2 *hist_out;         // the front-end kernels also leave the next block's history and tune vector (what k_mixhist_update
     double2 *v0_next;          // does; null: a launch of that kernel follows)
+    int out_f32;               // k_frontend_pk: the output stream holds floats (its readers are the float FIRs)
 };
 
 // Mixer alone (no half-band in front of the FIR chain: rates < 96 ksps).
@@ -683,6 +691,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WAVES_PER
     if (a.hist_out) mixhist_update(a, a.hist_out, a.v0_next, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
     const double2 *histp = a.hist + (long long)rx * a.H;
     double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
+    float *outf0 = sv_ptr_t<float>(a.out, rx, 0), *outf1 = sv_ptr_t<float>(a.out, rx, 1);
+    const bool of32 = a.out_f32 != 0;
+    auto put = [&](const long long i, const qk_f2 y) {
+        if (of32) { outf0[i] = y.x; outf1[i] = y.y; } else { out0[i] = (double)y.x; out1[i] = (double)y.y; }
+    };
     const long long dummy = (long long)a.out.plane_stride - a.out.hist - 1;     // last slot of the plane: never a sample
     // p^(64 it) in float for the samples of a chunk, p^64 and p^768 in double for the lane's own phasor
     const double2 P64 = a.mt.tabB[rx * 64 + 1], PCH = a.mt.tabB[rx * 64 + NIT];
@@ -766,7 +779,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WAVES_PER
         }
         // ---- the previous chunk's outputs leave, then the next chunk's samples start their trip ----
 #pragma unroll
-        for (int r = 0; r < RL; r++) { if (!(PK_SKIP & 2) || pend_y[r].x == 1.2345f) { out0[pend_i[r]] = (double)pend_y[r].x; out1[pend_i[r]] = (double)pend_y[r].y; } }
+        for (int r = 0; r < RL; r++) { if (!(PK_SKIP & 2) || pend_y[r].x == 1.2345f) put(pend_i[r], pend_y[r]); }
 
         const long long npos = pos + c;
         const int nc = npos < g_hi ? chunk_len(npos) : 0;
@@ -822,7 +835,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WAVES_PER
         pos = npos; c = nc;
     }
 #pragma unroll
-    for (int r = 0; r < RL; r++) { out0[pend_i[r]] = (double)pend_y[r].x; out1[pend_i[r]] = (double)pend_y[r].y; }
+    for (int r = 0; r < RL; r++) put(pend_i[r], pend_y[r]);
   }
 }
 
@@ -843,8 +856,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WAVES_PER
 // ------------------------------------------------------------------------------------------------
 #define FT_QB 8
 #define FT_LD 8
-template <int D, int NTH, int R, class T = double>
-__device__ __forceinline__ void fir_tile(const double *__restrict__ x, const T *__restrict__ hp, int TQP,
+template <int D, int NTH, int R, class T = double, class XI = double>
+__device__ __forceinline__ void fir_tile(const XI *__restrict__ x, const T *__restrict__ hp, int TQP,
                                          int first, int jb, int t_max, T *lds, T (&acc)[R])
 {
     constexpr int NO = NTH * R;
@@ -854,7 +867,7 @@ __device__ __forceinline__ void fir_tile(const double *__restrict__ x, const T *
     // FT_LD loads of a lane are in flight together (clamped index, so none is conditional): one load per trip left
     // the kernel waiting on memory latency with a few KB in flight per CU
     for (int u0 = threadIdx.x; u0 < count; u0 += FT_LD * NTH) {
-        double v[FT_LD];
+        XI v[FT_LD];
 #pragma unroll
         for (int i = 0; i < FT_LD; i++) {
             const int t = t_lo + u0 + i * NTH;
@@ -897,6 +910,7 @@ struct FirTArgs {
     const void *hp;            // [D][TQP] permuted taps, in the kernel's compute type
     int TQP, first, n_out;
     const int *rx_list;
+    int in_f32, out_f32;       // float kernels only: the input / output stream holds floats (front chain of the fp32 mode)
 };
 extern __shared__ __attribute__((aligned(16))) unsigned char ft_lds_raw[];
 template <int D, int NTH, int R, class T = double>
@@ -907,9 +921,20 @@ __global__ __launch_bounds__(NTH) void k_fir_tiled(FirTArgs a)
     const int plane = blockIdx.y;
     const int jb = blockIdx.x * (NTH * R);
     T acc[R];
-    fir_tile<D, NTH, R, T>(sv_ptr(a.in, rx, plane), static_cast<const T *>(a.hp), a.TQP, a.first, jb, a.first + D * (a.n_out - 1), ft_lds, acc);
-    double *__restrict__ o = sv_ptr(a.out, rx, plane) + jb + threadIdx.x * R;
     const int left = a.n_out - (jb + (int)threadIdx.x * R);
+    if constexpr (sizeof(T) == 4) {
+        if (a.in_f32) fir_tile<D, NTH, R, T, float>(sv_ptr_t<float>(a.in, rx, plane), static_cast<const T *>(a.hp), a.TQP, a.first, jb, a.first + D * (a.n_out - 1), ft_lds, acc);
+        else fir_tile<D, NTH, R, T>(sv_ptr(a.in, rx, plane), static_cast<const T *>(a.hp), a.TQP, a.first, jb, a.first + D * (a.n_out - 1), ft_lds, acc);
+        if (a.out_f32) {
+            float *__restrict__ of = sv_ptr_t<float>(a.out, rx, plane) + jb + threadIdx.x * R;
+#pragma unroll
+            for (int r = 0; r < R; r++) if (r < left) of[r] = acc[r];
+            return;
+        }
+    } else {
+        fir_tile<D, NTH, R, T>(sv_ptr(a.in, rx, plane), static_cast<const T *>(a.hp), a.TQP, a.first, jb, a.first + D * (a.n_out - 1), ft_lds, acc);
+    }
+    double *__restrict__ o = sv_ptr(a.out, rx, plane) + jb + threadIdx.x * R;
 #pragma unroll
     for (int r = 0; r < R; r++) if (r < left) o[r] = (double)acc[r];
 }
@@ -1959,7 +1984,7 @@ __global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
 // End of block: move the last `hist` samples of every stream to the front of its buffer.
 // ------------------------------------------------------------------------------------------------
 #define QK_MAX_TAILS 24
-struct TailDesc { double *d; long long rx_stride; int plane_stride, planes, hist, n; double *dst; };   // dst: same layout (ping-pong twin) or d itself
+struct TailDesc { double *d; long long rx_stride; int plane_stride, planes, hist, n; double *dst; int f32; };   // dst: same layout (ping-pong twin) or d itself; f32: the elements are floats
 struct TailArgs { TailDesc t[QK_MAX_TAILS]; int count; const int *rx_list; };
 __global__ __launch_bounds__(256) void k_save_tails(TailArgs a)
 {
@@ -1968,6 +1993,19 @@ __global__ __launch_bounds__(256) void k_save_tails(TailArgs a)
     if ((int)blockIdx.y >= td.planes || td.n <= 0) return;
     const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
     const long long off = (long long)rx * td.rx_stride + (long long)blockIdx.y * td.plane_stride;
+    if (td.f32) {
+        const float *fb = reinterpret_cast<const float *>(td.d) + off;
+        float *fd = reinterpret_cast<float *>(td.dst) + off;
+        for (int c0 = 0; c0 < td.hist; c0 += 256) {
+            const int i = c0 + threadIdx.x;
+            float v = 0.f;
+            if (i < td.hist) v = fb[i + td.n];
+            __syncthreads();
+            if (i < td.hist) fd[i] = v;
+            __syncthreads();
+        }
+        return;
+    }
     const double *base = td.d + off;
     double *dbase = td.dst + off;
     // dest[i] = src[i + n], i in [0, hist); ascending chunks keep reads ahead of writes when n < hist
