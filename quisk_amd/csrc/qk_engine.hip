@@ -1843,7 +1843,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         if (st.measure_div > 0 && out.n > 0 && d_list && !c.members.empty() && c.members[0] == 0) {
             // measure_audio: bank 0 only (quisk.c:1787-1790, 1873-1876, 1901-1904, 1980-1985, 2015-2018)
             if (fuse) fz_add(FS_MEASURE, out.view(), out.view(), out.planes, out.n, out.n);
-            else hipLaunchKernelGGL(k_measure_sum, dim3(1), dim3(256), 0, cs, out.view(), out.planes, out.n, e->d_ma);
+            else hipLaunchKernelGGL(k_measure_sum, dim3(out.n > 4096 ? std::min(32, (out.n + 1023) / 1024) : 1), dim3(256), 0, cs, out.view(), out.planes, out.n, e->d_ma);
             e->ma_count += out.n;
             const double fsr = (double)(e->decim_srate / st.measure_div);
             if ((double)e->ma_count >= fsr * e->ma_time) {

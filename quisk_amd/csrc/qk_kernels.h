@@ -952,7 +952,16 @@ __global__ __launch_bounds__(256) void k_interp(InterpArgs a)
     const double *__restrict__ p = sv_ptr(a.in, rx, plane) + i - a.delay;
     double acc = 0.0;
     const int terms = a.T / a.L;
-    for (int k = 0; k < terms; k++) acc = fma(p[-k], a.h[jj + k * a.L], acc);
+    // five terms' loads in flight together, the sum in the same order (one dependent trip to L2 per term was the kernel's time)
+    int k = 0;
+    for (; k + 5 <= terms; k += 5) {
+        double xv[5], hv[5];
+#pragma unroll
+        for (int u = 0; u < 5; u++) { xv[u] = p[-(k + u)]; hv[u] = a.h[jj + (k + u) * a.L]; }
+#pragma unroll
+        for (int u = 0; u < 5; u++) acc = fma(xv[u], hv[u], acc);
+    }
+    for (; k < terms; k++) acc = fma(p[-k], a.h[jj + k * a.L], acc);
     sv_ptr(a.out, rx, plane)[o] = acc * a.L;
 }
 
@@ -2484,14 +2493,17 @@ __global__ __launch_bounds__(256) void k_route_combine(const double2 *left, cons
     out[i] = make_double2(ml ? 0.0 : left[i].x, mr ? 0.0 : right[i].x);
 }
 // measure_audio (quisk.c:1787-1790, 2015-2018): the running sum of squares of receiver 0's detected audio.  One workgroup,
-// a fixed summation order (the reference adds sample by sample: the sums differ in the last bits).  acc[0] += sum.
+// (the reference adds sample by sample: the sums differ in the last bits; the test bound is 1e-9).  acc[0] += sum.
 __global__ __launch_bounds__(256) void k_measure_sum(StreamView in, int planes, int n, double *acc)
 {
     __shared__ double red[256];
+    // (long blocks: a few workgroups, a slice each, joined by an FP64 atomic add -- the single workgroup was 15 us on the
+    // chain's critical path at 32768 samples)
+    const int per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = min(n, lo + per);
     double s = 0.0;
     for (int pl = 0; pl < planes; pl++) {
         const double *p = sv_ptr(in, 0, pl);
-        for (int i = threadIdx.x; i < n; i += 256) s += p[i] * p[i];
+        for (int i = lo + threadIdx.x; i < hi; i += 256) s += p[i] * p[i];
     }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -2499,7 +2511,7 @@ __global__ __launch_bounds__(256) void k_measure_sum(StreamView in, int planes, 
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) acc[0] += red[0];
+    if (threadIdx.x == 0) { if (gridDim.x == 1) acc[0] += red[0]; else atomicAdd(&acc[0], red[0]); }
 }
 // ... and its close: measured_audio = sqrt(sum / count) / CLIP32 * 1e6; the sum starts again
 __global__ void k_measure_close(double *acc, double count)
