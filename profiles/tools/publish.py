@@ -15,9 +15,9 @@ def pmc(cfg, *subs):
     return json.loads(subprocess.run([sys.executable, os.path.join(P, "tools", "pmcsum.py"), G, tag, cfg] + list(subs), capture_output=True, text=True).stdout)
 src = "rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, TCC_HIT/MISS, SQ_*), one pass per counter block, profiles/tools/pmcset.sh"
 for cfg in ("c2", "c4", "c5"):
-    d = pmc(cfg, "k_frontend_wave", "k_fir_tiled<3", "k_fir_tiled<5", "k_fir_tiled<2", "k_agc_gain", "k_rxf_tiled")
+    d = pmc(cfg, "k_frontend_wave", "k_frontend_pk", "k_fir_tiled<3", "k_fir_tiled<5", "k_fir_tiled<2", "k_agc_gain", "k_rxf_tiled")
     json.dump(d, open("%s/%s_pmc_%s.json" % (P, rnd, cfg), "w"), indent=1)
-    fe = d.get("k_frontend_wave")
+    fe = d.get("k_frontend_pk") if cfg == "c5" and d.get("k_frontend_pk") else d.get("k_frontend_wave")
     if fe:
         out = {"source": src + "; summary in profiles/%s_pmc_%s.json" % (rnd, cfg), "kernel": fe["kernel"]}
         for k in ("hbm_bytes_per_launch", "hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "l2_hit_rate"):
