@@ -169,6 +169,10 @@ struct qk_engine {
                                // 26 us of host enqueue per block and costs 36 us of GPU time (one workgroup runs what the separate
                                // kernels spread over several): 160 against 150 us per block
     int fuse_max_in = 4096;    // ... up to this many samples behind the decimators, all receivers of the chain together (QK_FUSE_MAX)
+    bool small_mode = false;   // short blocks (max_block <= 4096, QK_SMALL_MODE): one HIP stream instead of four (a block is a string of
+                               // dependent launches: every hop between streams is an event packet's latency and buys nothing) and
+                               // the input block and the audio rows in pinned host memory that the kernels read and write
+                               // themselves (no copy commands, no pageable-memory staging)
     bool fe_packed = true;     // fp32 mode: the packed-FP32 front end k_frontend_pk (QK_FE_PACKED=0: the plane-per-lane float form)
     int rate_case = 0;
     // input
@@ -988,8 +992,13 @@ static int init_receivers(qk_engine *e)
     if (per_block > (1LL << 26)) return fail(QK_ERANGE, "max_block gives more than 2^26 audio samples per block (k_agc_gain tile index)");
     e->out_stride = (size_t)((per_block + 63) & ~63LL);
     e->gain_stride = (int)e->out_stride;
-    HIPCHECK(hipMalloc(&e->d_out, nslots * e->out_stride * sizeof(double2)));
-    HIPCHECK(hipMemset(e->d_out, 0, nslots * e->out_stride * sizeof(double2)));
+    if (e->small_mode) {
+        HIPCHECK(hipHostMalloc(&e->d_out, nslots * e->out_stride * sizeof(double2), hipHostMallocDefault));
+        memset(e->d_out, 0, nslots * e->out_stride * sizeof(double2));
+    } else {
+        HIPCHECK(hipMalloc(&e->d_out, nslots * e->out_stride * sizeof(double2)));
+        HIPCHECK(hipMemset(e->d_out, 0, nslots * e->out_stride * sizeof(double2)));
+    }
     HIPCHECK(hipMalloc(&e->d_ssb_carry, nrx * SSQ_N * sizeof(double)));
     HIPCHECK(hipMemset(e->d_ssb_carry, 0, nrx * SSQ_N * sizeof(double)));
     HIPCHECK(hipMalloc(&e->d_ssb_state, nrx * 4 * sizeof(int)));
@@ -1051,15 +1060,23 @@ static int engine_init(qk_engine *e)
 {
     const qk_config &cfg = e->cfg;
     HIPCHECK(hipSetDevice(cfg.device));
+    e->small_mode = cfg.max_block <= 4096;
+    if (const char *v = getenv("QK_SMALL_MODE")) e->small_mode = atoi(v) != 0;
     HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIPCHECK(hipStreamCreateWithFlags(&e->agc_stream, hipStreamNonBlocking));
-    bool apply_own = true;      // (QK_APPLY_STREAM=0: the limiter pass stays on the AGC's stream)
-    if (const char *v = getenv("QK_APPLY_STREAM")) apply_own = atoi(v) != 0;
-    if (apply_own) {
-        HIPCHECK(hipStreamCreateWithFlags(&e->apply_stream, hipStreamNonBlocking));
+    if (e->small_mode) {
+        // one stream under four names: the events between the stages become same-stream no-ops
+        e->agc_stream = e->apply_stream = e->fe_stream = e->stream;
         HIPCHECK(hipEventCreateWithFlags(&e->ev_gain, sync_event_flags()));
+    } else {
+        HIPCHECK(hipStreamCreateWithFlags(&e->agc_stream, hipStreamNonBlocking));
+        bool apply_own = true;      // (QK_APPLY_STREAM=0: the limiter pass stays on the AGC's stream)
+        if (const char *v = getenv("QK_APPLY_STREAM")) apply_own = atoi(v) != 0;
+        if (apply_own) {
+            HIPCHECK(hipStreamCreateWithFlags(&e->apply_stream, hipStreamNonBlocking));
+            HIPCHECK(hipEventCreateWithFlags(&e->ev_gain, sync_event_flags()));
+        }
+        HIPCHECK(hipStreamCreateWithFlags(&e->fe_stream, hipStreamNonBlocking));
     }
-    HIPCHECK(hipStreamCreateWithFlags(&e->fe_stream, hipStreamNonBlocking));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_fe, sync_event_flags()));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_fe2, sync_event_flags()));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_read[0], sync_event_flags()));
@@ -1107,7 +1124,8 @@ static int engine_init(qk_engine *e)
         HIPCHECK(hipMalloc(&e->d_tw4096, sizeof(double2) * 4096));
         HIPCHECK(hipMemcpy(e->d_tw4096, tw.data(), sizeof(double2) * 4096, hipMemcpyHostToDevice));
     }
-    HIPCHECK(hipMalloc(&e->d_in, (size_t)cfg.max_block * sizeof(double2)));
+    if (e->small_mode) HIPCHECK(hipHostMalloc(&e->d_in, (size_t)std::max(cfg.max_block, 1) * sizeof(double2), hipHostMallocDefault));
+    else HIPCHECK(hipMalloc(&e->d_in, (size_t)cfg.max_block * sizeof(double2)));
     {
         const int nseg = (cfg.max_block + DC_SEG - 1) / DC_SEG;
         HIPCHECK(hipMalloc(&e->d_cond, (size_t)cfg.max_block * sizeof(double2)));
@@ -2425,6 +2443,7 @@ void qk_destroy(qk_engine *e)
                     (void *)e->d_bs_out, (void *)e->d_bs_X, (void *)e->d_bs_max})
         if (p) hipFree(p);
     for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
+    if (e->small_mode) { if (e->d_in) hipHostFree(e->d_in); if (e->d_out) hipHostFree(e->d_out); e->d_in = nullptr; e->d_out = nullptr; }
     void *ptrs[] = {e->d_nb_x[0], e->d_nb_x[1], e->d_nb_mag[0], e->d_nb_mag[1], e->d_nb_p[0], e->d_nb_p[1], e->d_nb_y, e->d_nb_loc, e->d_nb_segsum,
                     e->d_nb_segbase, e->d_nb_S, e->d_nb_words, e->d_nb_any, e->d_cond, e->d_dc_seg_end, e->d_dc_seg_in, e->d_dc_state, e->d_dc_partial, e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps, e->d_cls,
                     e->d_mode, e->d_release_gain, e->d_coefs_f, e->d_taps_f, e->d_agc, e->d_agc_started, e->d_gains, e->d_agc_mag, e->d_sq_state, e->d_sq_partial, e->d_sq_flag, e->d_out,
@@ -2452,8 +2471,8 @@ void qk_destroy(qk_engine *e)
                     (void *)e->d_ag_avg}) if (p) hipFree(p);
     for (void *p : {(void *)e->d_scan_avg, (void *)e->d_raw_rows, (void *)e->d_rfb_x[0], (void *)e->d_rfb_x[1], (void *)e->d_rfb_x[2], (void *)e->d_rfb_y, (void *)e->d_rfb_t}) if (p) hipFree(p);
     for (auto &ev : e->ev_pool) if (ev) hipEventDestroy(ev);
-    if (e->agc_stream) { hipStreamSynchronize(e->agc_stream); hipStreamDestroy(e->agc_stream); }
-    if (e->apply_stream) { hipStreamSynchronize(e->apply_stream); hipStreamDestroy(e->apply_stream); }
+    if (e->agc_stream && e->agc_stream != e->stream) { hipStreamSynchronize(e->agc_stream); hipStreamDestroy(e->agc_stream); }
+    if (e->apply_stream && e->apply_stream != e->stream) { hipStreamSynchronize(e->apply_stream); hipStreamDestroy(e->apply_stream); }
     if (e->ev_gain) hipEventDestroy(e->ev_gain);
     if (e->d_gains2) hipFree(e->d_gains2);
     if (e->d_agc_started2) hipFree(e->d_agc_started2);
@@ -2465,7 +2484,7 @@ void qk_destroy(qk_engine *e)
     if (e->ev_fe) hipEventDestroy(e->ev_fe);
     if (e->ev_fe2) hipEventDestroy(e->ev_fe2);
     for (auto &ev : e->ev_read) if (ev) hipEventDestroy(ev);
-    if (e->fe_stream) hipStreamDestroy(e->fe_stream);
+    if (e->fe_stream && e->fe_stream != e->stream) hipStreamDestroy(e->fe_stream);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -2474,9 +2493,9 @@ void qk_destroy(qk_engine *e)
     if (!(e)) return fail(QK_EINVAL, "null engine");                     \
     std::lock_guard<std::mutex> _lk((e)->mu);                            \
     HIPCHECK(hipSetDevice((e)->cfg.device))
-#define SYNC_ALL(e) do { HIPCHECK(hipStreamSynchronize((e)->fe_stream)); HIPCHECK(hipStreamSynchronize((e)->stream)); \
-                         HIPCHECK(hipStreamSynchronize((e)->agc_stream)); \
-                         if ((e)->apply_stream) HIPCHECK(hipStreamSynchronize((e)->apply_stream)); } while (0)
+#define SYNC_ALL(e) do { HIPCHECK(hipStreamSynchronize((e)->stream)); \
+                         if (!(e)->small_mode) { HIPCHECK(hipStreamSynchronize((e)->fe_stream)); HIPCHECK(hipStreamSynchronize((e)->agc_stream)); \
+                             if ((e)->apply_stream) HIPCHECK(hipStreamSynchronize((e)->apply_stream)); } } while (0)
 #define RX_CHECK(e, rx) if ((rx) < 0 || (rx) >= (e)->nrx) return fail(QK_ERANGE, "receiver index out of range")
 // after a synchronisation: a hand-over inside k_agc_gain that ran out of polls left NaN gains behind (qk_kernels.h, AGC_SPIN_LIMIT)
 #define AGC_ABORT_CHECK(e) do { if ((e)->h_agc_abort && *(e)->h_agc_abort) \
@@ -2676,7 +2695,8 @@ int qk_process_samples(qk_engine *e, const double *iq_host, int n)
     if (!iq_host && n > 0) return fail(QK_EINVAL, "null sample pointer");
     if (n > 0) {
         SYNC_ALL(e);      // the previous block may still read d_in
-        HIPCHECK(hipMemcpyAsync(e->d_in, iq_host, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, e->fe_stream));
+        if (e->small_mode) memcpy(e->d_in, iq_host, (size_t)n * sizeof(double2));      // (pinned: the kernels read it over the bus)
+        else HIPCHECK(hipMemcpyAsync(e->d_in, iq_host, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, e->fe_stream));
     }
     return process_device(e, e->d_in, n);
 }
@@ -2720,11 +2740,17 @@ int qk_audio_count(qk_engine *e, int rx)
 int qk_pull_audio(qk_engine *e, int rx, double *dst, int cap)
 {
     ENGINE_ENTER(e); RX_CHECK(e, rx);
+    const int m = std::min(e->out_count[rx], cap);
+    if (m > 0 && !dst) return fail(QK_EINVAL, "null destination");
+    if (e->small_mode) {
+        SYNC_ALL(e);
+        if (m > 0) memcpy(dst, e->d_out + (size_t)rx * e->out_stride, (size_t)m * sizeof(double2));     // (the rows are host memory)
+        AGC_ABORT_CHECK(e);
+        return m;
+    }
     HIPCHECK(hipStreamSynchronize(e->agc_stream));       // the AGC pass writes the audio output
     if (e->apply_stream) HIPCHECK(hipStreamSynchronize(e->apply_stream));
-    const int m = std::min(e->out_count[rx], cap);
     if (m > 0) {
-        if (!dst) return fail(QK_EINVAL, "null destination");
         HIPCHECK(hipMemcpyAsync(dst, e->d_out + (size_t)rx * e->out_stride, (size_t)m * sizeof(double2),
                                 hipMemcpyDeviceToHost, e->stream));
     }
@@ -2743,6 +2769,13 @@ int qk_pull_audio_all(qk_engine *e, double *dst, size_t stride, int *counts)
         const int m = e->out_count[r];
         if ((size_t)m > stride) return fail(QK_ERANGE, "stride smaller than the audio block");
         counts[r] = m;
+    }
+    if (e->small_mode) {
+        SYNC_ALL(e);
+        for (int r = 0; r < e->nrx; r++)
+            memcpy(dst + 2 * (size_t)r * stride, e->d_out + (size_t)r * e->out_stride, std::min(stride, e->out_stride) * sizeof(double2));
+        AGC_ABORT_CHECK(e);
+        return QK_OK;
     }
     HIPCHECK(hipMemcpy2DAsync(dst, stride * sizeof(double2), e->d_out, e->out_stride * sizeof(double2),
                               std::min(stride, e->out_stride) * sizeof(double2), e->nrx, hipMemcpyDeviceToHost, e->stream));
@@ -3434,7 +3467,7 @@ int qk_export_audio_device(qk_engine *e, double *dst_dev, size_t dst_stride)
     if (w > dst_stride) return fail(QK_ERANGE, "stride smaller than the audio block");
     if (w > 0)
         HIPCHECK(hipMemcpy2DAsync(dst_dev, dst_stride * sizeof(double2), e->d_out, e->out_stride * sizeof(double2),
-                                  w * sizeof(double2), e->nrx, hipMemcpyDeviceToDevice, e->stream));
+                                  w * sizeof(double2), e->nrx, e->small_mode ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, e->stream));
     SYNC_ALL(e);
     AGC_ABORT_CHECK(e);
     return QK_OK;
