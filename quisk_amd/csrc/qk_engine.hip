@@ -1478,7 +1478,8 @@ static int feed_spectrum(qk_engine *e, const double2 *x, int n)
             // only the head of a frame is ever read back: keep the first data_width samples
             if (e->fft_fill < e->fftW) {
                 const int c = std::min(take, e->fftW - e->fft_fill);
-                HIPCHECK(hipMemcpyAsync(e->d_fft_stage + e->fft_fill, x + pos, sizeof(double2) * c, hipMemcpyDeviceToDevice, e->fe_stream));
+                if (e->small_mode) hipLaunchKernelGGL(k_copy_c, dim3((c + 255) / 256), dim3(256), 0, e->fe_stream, x + pos, e->d_fft_stage + e->fft_fill, c);
+                else HIPCHECK(hipMemcpyAsync(e->d_fft_stage + e->fft_fill, x + pos, sizeof(double2) * c, hipMemcpyDeviceToDevice, e->fe_stream));
             }
             e->fft_fill += take; pos += take;
             if (e->fft_fill == N) { int rc = raw_frame(e, e->d_fft_stage); if (rc != QK_OK) return rc; e->fft_fill = 0; }
@@ -1494,7 +1495,9 @@ static int feed_spectrum(qk_engine *e, const double2 *x, int n)
             continue;
         }
         const int take = std::min(N - e->fft_fill, n - pos);
-        HIPCHECK(hipMemcpyAsync(e->d_fft_stage + e->fft_fill, x + pos, sizeof(double2) * take, hipMemcpyDeviceToDevice, e->fe_stream));
+        // (short blocks: the input is pinned host memory and a launch costs the host less than a copy command)
+        if (e->small_mode) hipLaunchKernelGGL(k_copy_c, dim3((take + 255) / 256), dim3(256), 0, e->fe_stream, x + pos, e->d_fft_stage + e->fft_fill, take);
+        else HIPCHECK(hipMemcpyAsync(e->d_fft_stage + e->fft_fill, x + pos, sizeof(double2) * take, hipMemcpyDeviceToDevice, e->fe_stream));
         e->fft_fill += take; pos += take;
         if (e->fft_fill == N) { fft_frames(e, e->d_fft_stage, 1); e->fft_fill = 0; }
     }
@@ -1780,8 +1783,10 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             if (n_in > 0 && fuse) {
                 fz_add(FS_RXF, in.view(), out.view(), 2, n_in, n_in).sub = st.rxf_kind;
             } else if (n_in > 0) {
+                // measure_audio's sum rides in the kernel's epilogue where this stage is the one it measures
+                const bool ma_here = st.measure_div > 0 && d_list && !c.members.empty() && c.members[0] == 0;
                 RxfArgs a{in.view(), out.view(), e->fp32 ? (const void *)e->d_taps_f : (const void *)e->d_taps, e->d_ntaps, e->d_mode, e->tap_cap, n_in,
-                          st.rxf_kind, d_list};
+                          st.rxf_kind, d_list, ma_here ? e->d_ma : nullptr};
                 Timer tm(e, st.timer, cs);
                 int nmax = 0;
                 for (int r : c.members) nmax = std::max(nmax, e->ntaps[r]);
@@ -1861,7 +1866,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         if (st.measure_div > 0 && out.n > 0 && d_list && !c.members.empty() && c.members[0] == 0) {
             // measure_audio: bank 0 only (quisk.c:1787-1790, 1873-1876, 1901-1904, 1980-1985, 2015-2018)
             if (fuse) fz_add(FS_MEASURE, out.view(), out.view(), out.planes, out.n, out.n);
-            else hipLaunchKernelGGL(k_measure_sum, dim3(out.n > 4096 ? std::min(32, (out.n + 1023) / 1024) : 1), dim3(256), 0, cs, out.view(), out.planes, out.n, e->d_ma);
+            else if (st.kind != ST_RXF) hipLaunchKernelGGL(k_measure_sum, dim3(out.n > 4096 ? std::min(32, (out.n + 1023) / 1024) : 1), dim3(256), 0, cs, out.view(), out.planes, out.n, e->d_ma);
             e->ma_count += out.n;
             const double fsr = (double)(e->decim_srate / st.measure_div);
             if ((double)e->ma_count >= fsr * e->ma_time) {
@@ -1905,13 +1910,13 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
     return QK_OK;
 }
 
-static void add_tails(TailArgs &ta, Chain &c, int skip)
+static void add_tails(TailArgs &ta, Chain &c, int skip, const int *rx_list = nullptr, int n_rx = 0)
 {
     for (int i = 0; i < (int)c.streams.size(); i++) {
         Stream &s = c.streams[i];
         if (i == skip || s.hist <= 0 || s.n <= 0) continue;
         if (ta.count >= QK_MAX_TAILS) break;
-        ta.t[ta.count++] = TailDesc{s.d, s.rx_stride(), s.hist + s.cap, s.planes, s.hist, s.n, s.d, s.f32 ? 1 : 0};
+        ta.t[ta.count++] = TailDesc{s.d, s.rx_stride(), s.hist + s.cap, s.planes, s.hist, s.n, s.d, s.f32 ? 1 : 0, rx_list, n_rx};
     }
 }
 
@@ -2333,8 +2338,12 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     HIPCHECK(hipEventRecord(e->ev_agc[par], agc_ev_stream));
     // ---- carry stream tails ----
     {
+        // (short blocks: the front chain's and the classes' tails leave in ONE launch, each entry with its own receiver list)
+        const bool merge = e->small_mode;
+        TailArgs all{}; all.count = 0; all.rx_list = nullptr;
         TailArgs ta{}; ta.count = 0; ta.rx_list = nullptr;
-        add_tails(ta, F, 0);        // stream 0 is carried by the head copy
+        if (merge) add_tails(all, F, 0, nullptr, e->nrx);
+        else add_tails(ta, F, 0);        // stream 0 is carried by the head copy
         if (ta.count) hipLaunchKernelGGL(k_save_tails, dim3(ta.count, 2, e->nrx), dim3(256), 0, e->stream, ta);
         if (e->mf_mode > 0 && e->mf_chain.built) {
             TailArgs tm{}; tm.count = 0; tm.rx_list = nullptr;
@@ -2348,11 +2357,22 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             const int nl = (int)c.members.size();
             if (!nl) continue;
             TailArgs tb{}; tb.count = 0; tb.rx_list = c.d_members;
-            add_tails(tb, c, c.play);
             Stream &play = c.streams[c.play];
-            if (play.n > 0 && tb.count < QK_MAX_TAILS)
-                tb.t[tb.count++] = TailDesc{play.d, play.rx_stride(), play.hist + play.cap, play.planes, play.hist, play.n, c.play_alt};
+            int extra = 1;
+            for (auto &sx : c.streams) if (sx.hist > 0 && sx.n > 0) extra++;
+            const bool into_all = merge && all.count + extra <= QK_MAX_TAILS;
+            TailArgs &dst_t = into_all ? all : tb;
+            add_tails(dst_t, c, c.play, into_all ? c.d_members : nullptr, into_all ? nl : 0);
+            if (play.n > 0 && dst_t.count < QK_MAX_TAILS)
+                dst_t.t[dst_t.count++] = TailDesc{play.d, play.rx_stride(), play.hist + play.cap, play.planes, play.hist, play.n, c.play_alt, 0,
+                                                  into_all ? c.d_members : nullptr, into_all ? nl : 0};
             if (tb.count) hipLaunchKernelGGL(k_save_tails, dim3(tb.count, 2, nl), dim3(256), 0, e->stream, tb);
+            // (the merged launch goes out in front of the first memset below, or behind the loop)
+            if (into_all && c.n_out > 0) {
+                bool any_first = false;
+                for (int r : c.members) if (!e->agc_started[r]) any_first = true;
+                if (any_first && all.count) { hipLaunchKernelGGL(k_save_tails, dim3(all.count, 2, e->nrx), dim3(256), 0, e->stream, all); all.count = 0; }
+            }
             if (c.n_out > 0) {
                 // A receiver's first process_agc call returns the block untouched and does NOT store it in the
                 // delay ring (quisk.c:2033-2050): the ring (= the play stream's history) stays zero.
@@ -2365,6 +2385,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
                 }
             }
         }
+        if (all.count) hipLaunchKernelGGL(k_save_tails, dim3(all.count, 2, e->nrx), dim3(256), 0, e->stream, all);
         for (auto &r : e->routes) {
             if (!r.live) continue;
             Chain &t = r.tail;

@@ -1043,6 +1043,7 @@ struct RxfArgs {
     const int *mode;           // [rx] rx_mode_type
     int tap_cap, n, kind;
     const int *rx_list;
+    double *ma_acc;            // measure_audio (quisk.c:1787-1790): receiver 0's outputs squared are added here (null: not this stage)
 };
 template <int NTH, int R, class T = double>
 __global__ __launch_bounds__(NTH) void k_rxf_tiled(RxfArgs a)
@@ -1069,18 +1070,24 @@ __global__ __launch_bounds__(NTH) void k_rxf_tiled(RxfArgs a)
     }
     double *o0 = sv_ptr(a.out, rx, 0) + j0;
     const int left = a.n - j0;
+    double msum = 0.0;          // sum of the squares of what this lane stores
     if (a.kind == 0) {
         const int m = a.mode[rx];
         const bool lower = (m == 0 /*CWL*/ || m == 2 /*LSB*/ || m == 8 /*DGT_L*/);
 #pragma unroll
-        for (int r = 0; r < R; r++) if (r < left) o0[r] = (double)(lower ? ar[r] + ai[r] : ar[r] - ai[r]);
+        for (int r = 0; r < R; r++) if (r < left) { const double v = (double)(lower ? ar[r] + ai[r] : ar[r] - ai[r]); o0[r] = v; msum += v * v; }
     } else if (a.kind == 1) {
 #pragma unroll
-        for (int r = 0; r < R; r++) if (r < left) o0[r] = hypot((double)ar[r], (double)ai[r]);
+        for (int r = 0; r < R; r++) if (r < left) { const double v = hypot((double)ar[r], (double)ai[r]); o0[r] = v; msum += v * v; }
     } else {
         double *o1 = sv_ptr(a.out, rx, 1) + j0;
 #pragma unroll
-        for (int r = 0; r < R; r++) if (r < left) { o0[r] = (double)ar[r]; o1[r] = (double)ai[r]; }
+        for (int r = 0; r < R; r++) if (r < left) { o0[r] = (double)ar[r]; o1[r] = (double)ai[r]; msum += (double)ar[r] * (double)ar[r] + (double)ai[r] * (double)ai[r]; }
+    }
+    if (a.ma_acc && rx == 0) {  // (wave-uniform: one atomic per wave; the order of the adds is free within the test's 1e-9)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) msum += __shfl_xor(msum, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.ma_acc, msum);
     }
 }
 
@@ -1993,14 +2000,16 @@ __global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
 // End of block: move the last `hist` samples of every stream to the front of its buffer.
 // ------------------------------------------------------------------------------------------------
 #define QK_MAX_TAILS 24
-struct TailDesc { double *d; long long rx_stride; int plane_stride, planes, hist, n; double *dst; int f32; };   // dst: same layout (ping-pong twin) or d itself; f32: the elements are floats
+struct TailDesc { double *d; long long rx_stride; int plane_stride, planes, hist, n; double *dst; int f32; const int *rx_list; int n_rx; };   // dst: same layout (ping-pong twin) or d itself; f32: the elements are floats; rx_list / n_rx: this entry's own receivers (n_rx > 0) in a launch that serves several chains
 struct TailArgs { TailDesc t[QK_MAX_TAILS]; int count; const int *rx_list; };
 __global__ __launch_bounds__(256) void k_save_tails(TailArgs a)
 {
     // grid (count, 2 planes, receivers)
     const TailDesc td = a.t[blockIdx.x];
     if ((int)blockIdx.y >= td.planes || td.n <= 0) return;
-    const int rx = a.rx_list ? a.rx_list[blockIdx.z] : blockIdx.z;
+    if (td.n_rx > 0 && (int)blockIdx.z >= td.n_rx) return;
+    const int *rl = td.n_rx > 0 ? td.rx_list : a.rx_list;
+    const int rx = rl ? rl[blockIdx.z] : blockIdx.z;
     const long long off = (long long)rx * td.rx_stride + (long long)blockIdx.y * td.plane_stride;
     if (td.f32) {
         const float *fb = reinterpret_cast<const float *>(td.d) + off;
