@@ -165,9 +165,10 @@ struct qk_engine {
     int fe_slots = 2304;       // resident one-wave workgroups of k_frontend_wave on the whole chip (occupancy query)
     int fe_share = 100;        // percent of the resident slots the front end may occupy (QK_FE_SHARE)
     int fe_rounds = 2;         // front-end workgroups launched per resident slot (QK_FE_ROUNDS)
-    bool fuse_chains = false;  // short blocks: a class chain as one launch (k_chain_fused, QK_FUSE=1).  Off: measured at config 1 it saves
-                               // 26 us of host enqueue per block and costs 36 us of GPU time (one workgroup runs what the separate
-                               // kernels spread over several): 160 against 150 us per block
+    bool fuse_chains = false;  // short blocks (small_mode; QK_FUSE overrides): a class chain, with the front chain's FIRs in front of it where
+                               // one class holds every receiver, as one launch (k_chain_fused)
+    FusedArgs fz_front{};      // short blocks: the front chain's FIR stages wait here for the class chain's launch (fz_defer), so that the
+    bool fz_defer = false;     // decimators behind the front end and the whole class chain are ONE launch
     int fuse_max_in = 4096;    // ... up to this many samples behind the decimators, all receivers of the chain together (QK_FUSE_MAX)
     bool small_mode = false;   // short blocks (max_block <= 4096, QK_SMALL_MODE): one HIP stream instead of four (a block is a string of
                                // dependent launches: every hop between streams is an event packet's latency and buys nothing) and
@@ -917,6 +918,7 @@ static int init_receivers(qk_engine *e)
     if (const char *v = getenv("QK_FE_SHARE")) e->fe_share = std::max(5, std::min(100, atoi(v)));
     if (const char *v = getenv("QK_FE_ROUNDS")) e->fe_rounds = std::max(1, std::min(16, atoi(v)));
     if (const char *v = getenv("QK_FE_PACKED")) e->fe_packed = atoi(v) != 0;
+    e->fuse_chains = e->small_mode;
     if (const char *v = getenv("QK_FUSE")) e->fuse_chains = atoi(v) != 0;
     if (const char *v = getenv("QK_FUSE_MAX")) e->fuse_max_in = std::max(1, atoi(v));
     mark_float_streams(e);
@@ -1674,8 +1676,9 @@ static bool chain_fusable(const qk_engine *e, const Chain &c, const Stream &inpu
 {
     // (one workgroup per receiver: worth it only while the whole launch is a few thousand samples -- with 128 receivers of
     // 819 samples each the separate, wider kernels are twice as fast)
-    if (!e->fuse_chains || &c == &e->front || input.n <= 0 || (long long)input.n * std::max(1, nlist) > e->fuse_max_in) return false;
+    if (!e->fuse_chains || (&c == &e->front && !e->fz_defer) || input.n <= 0 || (long long)input.n * std::max(1, nlist) > e->fuse_max_in) return false;
     if ((int)c.stages.size() + 2 > QK_FUSED_MAX) return false;
+    for (const auto &sx : c.streams) if (sx.f32) return false;           // (the fused stages read and write doubles)
     for (const auto &st : c.stages) {
         if (st.kind == ST_RESAMP || st.in_after || st.out_after) return false;
         if (st.kind == ST_FIR && (e->fp32 && st.hf ? false : st.h == nullptr)) return false;
@@ -1894,6 +1897,24 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
         }
     }
     if (c.shared >= 0) c.streams[c.shared].n += c.shared_n1;      // what the ring took in this block: both users' samples
+    if (fuse && &c == &e->front) {          // deferred: the class chain's launch takes these stages along
+        e->fz_front = fz;
+        return QK_OK;
+    }
+    if (e->fz_front.nst > 0 && &c != &e->front) {
+        if (fuse && fz.nst > 0 && fz.nst + e->fz_front.nst <= QK_FUSED_MAX && nlist == e->nrx) {
+            const int k = e->fz_front.nst;
+            for (int i = fz.nst - 1; i >= 0; i--) fz.st[i + k] = fz.st[i];
+            for (int i = 0; i < k; i++) fz.st[i] = e->fz_front.st[i];
+            fz.nst += k;
+        } else {                            // (the class chain did not fuse after all: the waiting stages go out alone)
+            FusedArgs &ff = e->fz_front;
+            ff.rx_list = nullptr; ff.n_rx = e->nrx; ff.tap_cap = e->tap_cap;
+            if (e->fp32) hipLaunchKernelGGL(k_chain_fused<float>, dim3(e->nrx), dim3(256), 0, cs, ff);
+            else hipLaunchKernelGGL(k_chain_fused<double>, dim3(e->nrx), dim3(256), 0, cs, ff);
+        }
+        e->fz_front.nst = 0;
+    }
     if (fuse && fz.nst > 0) {
         fz.rx_list = d_list; fz.n_rx = nlist; fz.tap_cap = e->tap_cap;
         fz.taps = e->fp32 ? (const void *)e->d_taps_f : (const void *)e->d_taps; fz.ntaps = e->d_ntaps; fz.mode = e->d_mode;
@@ -2119,6 +2140,9 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             const int nspans = (int)((consumed + span - 1) / span);
             fa.span_len = (int)span; fa.nspans = nspans;
             fa.hist_out = e->d_mixhist[e->pp ^ 1]; fa.v0_next = e->d_v0[e->pp ^ 1];
+            if (fe_writes && F.streams[0].hist > 0 && F.front_last_n > 0) {     // the head copy rides along too
+                fa.head_src = F.front_alt; fa.head_hist = F.streams[0].hist; fa.head_n = F.front_last_n;
+            }
             switch (S) {
             case 1: launch_frontend<1>(e, fa, nspans); break;
             case 2: launch_frontend<2>(e, fa, nspans); break;
@@ -2142,7 +2166,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         Stream &f0 = F.streams[0];
         TailArgs th{}; th.count = 1; th.rx_list = nullptr;
         th.t[0] = TailDesc{F.front_alt, f0.rx_stride(), f0.hist + f0.cap, f0.planes, f0.hist, F.front_last_n, f0.d, f0.f32 ? 1 : 0};
-        if (f0.hist > 0 && F.front_last_n > 0)
+        if (f0.hist > 0 && F.front_last_n > 0 && !fa.head_src)
             hipLaunchKernelGGL(k_save_tails, dim3(1, 2, e->nrx), dim3(256), 0, e->stream, th);
         F.front_last_n = f0.n;
     }
@@ -2152,6 +2176,17 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         HIPCHECK(hipStreamWaitEvent(e->stream, evf, 0));
     }
     // ---- remaining integer decimation, all receivers ----
+    // short blocks, one class with every receiver in order, nothing between the front chain and it: one fused launch for both
+    e->fz_defer = false; e->fz_front.nst = 0;
+    if (e->small_mode && e->fuse_chains && e->mf_mode == 0 && e->routes.empty()) {
+        int active = 0, cl_a = -1;
+        for (int cl = 0; cl < CL_COUNT; cl++) if (!e->cls_chain[cl].members.empty()) { active++; cl_a = cl; }
+        if (active == 1 && (int)e->cls_chain[cl_a].members.size() == e->nrx) {
+            bool ident = true;
+            for (int i = 0; i < e->nrx; i++) if (e->cls_chain[cl_a].members[i] != i) ident = false;
+            e->fz_defer = ident;
+        }
+    }
     int rc = run_chain(e, F, F.streams[0], nullptr, e->nrx, e->stream);
     if (rc != QK_OK) return rc;
     const Stream &dec = F.streams[F.aud];

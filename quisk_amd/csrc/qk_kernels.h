@@ -115,6 +115,8 @@ struct FrontArgs {
     double2 *hist_out;         // the front-end kernels also leave the next block's history and tune vector (what k_mixhist_update
     double2 *v0_next;          // does; null: a launch of that kernel follows)
     int out_f32;               // k_frontend_pk: the output stream holds floats (its readers are the float FIRs)
+    const double *head_src;    // the output stream is double-buffered: the last head_hist elements of the previous block (head_n of them,
+    int head_hist, head_n;     // in the twin head_src) go in front of this block's first output (null: a k_save_tails launch does it)
 };
 
 // Mixer alone (no half-band in front of the FIR chain: rates < 96 ksps).
@@ -147,6 +149,18 @@ __device__ __forceinline__ void mixhist_update(const FrontArgs &a, double2 *hist
     }
     if (first == 0)
         v0_next[rx] = on ? mix_w(a.mt, rx, a.n) : a.mt.v0[rx];
+}
+// the head copy of the front end's double-buffered output stream, spread over the grid like mixhist_update (elements are floats
+// when the stream holds floats): dst[plane][i] = src[plane][i + n], i < hist
+__device__ __forceinline__ void front_head_copy(const FrontArgs &a, const int rx, const int first, const int stride)
+{
+    const long long base = (long long)rx * a.out.rx_stride;
+    for (int i = first; i < 2 * a.head_hist; i += stride) {
+        const int pl = i >= a.head_hist, k = i - pl * a.head_hist;
+        const long long o = base + (long long)pl * a.out.plane_stride + k;
+        if (a.out_f32) reinterpret_cast<float *>(a.out.d)[o] = reinterpret_cast<const float *>(a.head_src)[o + a.head_n];
+        else a.out.d[o] = a.head_src[o + a.head_n];
+    }
 }
 __global__ __launch_bounds__(256) void k_mixhist_update(FrontArgs a, double2 *hist_out, double2 *v0_next)
 {
@@ -417,6 +431,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FE_WAVES_PER
     const int mix = a.mt.mix_on[rx];
     // the next block's history (its own buffer: nobody reads it in this launch), a sample or two per lane across the grid
     if (a.hist_out) mixhist_update(a, a.hist_out, a.v0_next, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
+    if (a.head_src) front_head_copy(a, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
     const double2 *histp = a.hist + (long long)rx * a.H;
     double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
     const long long dummy = (long long)a.out.plane_stride - a.out.hist - 1;     // last slot of the plane: never a sample
@@ -689,6 +704,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WAVES_PER
     const int mix = a.mt.mix_on[rx];
     // the next block's history (its own buffer: nobody reads it in this launch), a sample or two per lane across the grid
     if (a.hist_out) mixhist_update(a, a.hist_out, a.v0_next, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
+    if (a.head_src) front_head_copy(a, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
     const double2 *histp = a.hist + (long long)rx * a.H;
     double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
     float *outf0 = sv_ptr_t<float>(a.out, rx, 0), *outf1 = sv_ptr_t<float>(a.out, rx, 1);
@@ -2548,6 +2564,7 @@ struct FStage {
     int kind, planes, n_in, n_out, D, L, T, TQP, first, delay, sub, pad;
 };
 #define QK_FUSED_MAX 14
+#define FZ_LDS 6144          // elements of LDS a fused stage may stage its window and taps in (48 KiB of doubles)
 struct FusedArgs {
     int nst, tap_cap, n_rx, sq_pstride;
     const int *rx_list;
@@ -2562,6 +2579,7 @@ __global__ __launch_bounds__(256) void k_chain_fused(FusedArgs a)
 {
     __shared__ double red[256];
     __shared__ double part[256];
+    __shared__ T fz_lds[FZ_LDS];
     const int rx = a.rx_list ? a.rx_list[blockIdx.x] : blockIdx.x;
     const int tid = threadIdx.x;
     for (int s = 0; s < a.nst; s++) {
@@ -2570,6 +2588,32 @@ __global__ __launch_bounds__(256) void k_chain_fused(FusedArgs a)
         case FS_FIR: {          // fir_tile: branch by branch, taps in order, one fma each
             const T *__restrict__ hp = static_cast<const T *>(st.h);
             const int D = st.D, TQP = st.TQP;
+            const int W = D * (st.n_out + TQP - 1);             // input window of one plane: indices lo .. lo + W - 1
+            const int lo = st.first - (D - 1) - D * (TQP - 1);
+            if (st.planes * W + D * TQP <= FZ_LDS) {
+                // window and taps through LDS: a chain of T dependent fma per output, its operands a few cycles away
+                // instead of a trip to L2 each (the same operations in the same order)
+                T *X = fz_lds, *H = fz_lds + st.planes * W;
+                for (int pl = 0; pl < st.planes; pl++) {
+                    const double *__restrict__ x = sv_ptr(st.in, rx, pl) + lo;
+                    for (int i = tid; i < W; i += 256) X[pl * W + i] = (T)x[i];
+                }
+                for (int i = tid; i < D * TQP; i += 256) H[i] = hp[i];
+                __syncthreads();
+                for (int o = tid; o < st.planes * st.n_out; o += 256) {
+                    const int plane = o / st.n_out, j = o - plane * st.n_out;
+                    const T *__restrict__ x = X + plane * W + (st.first + D * j - lo);
+                    T acc = T(0);
+                    for (int p = 0; p < D; p++) {
+                        const T *__restrict__ h = H + p * TQP;
+                        const T *__restrict__ xp = x - p;
+#pragma unroll 8
+                        for (int q = 0; q < TQP; q++) acc = fma(xp[-D * q], h[q], acc);
+                    }
+                    sv_ptr(st.out, rx, plane)[j] = (double)acc;
+                }
+                break;
+            }
             for (int o = tid; o < st.planes * st.n_out; o += 256) {
                 const int plane = o / st.n_out, j = o - plane * st.n_out;
                 const double *__restrict__ x = sv_ptr(st.in, rx, plane) + st.first + D * j;
@@ -2592,6 +2636,32 @@ __global__ __launch_bounds__(256) void k_chain_fused(FusedArgs a)
             const bool lower = (m == 0 /*CWL*/ || m == 2 /*LSB*/ || m == 8 /*DGT_L*/);
             const double *__restrict__ pr = sv_ptr(st.in, rx, 0), *__restrict__ pi = sv_ptr(st.in, rx, 1);
             double *o0 = sv_ptr(st.out, rx, 0);
+            const int W = st.n_in + TQP - 1;                    // indices -(TQP - 1) .. n_in - 1 of either plane
+            if (N > 0 && 2 * W + 2 * TQP + 2 * st.n_in <= FZ_LDS) {
+                // both planes' windows, both tap sets and the two chains' results through LDS; the I chain and the Q chain of an
+                // output run on two lanes
+                T *X = fz_lds, *H = X + 2 * W, *Rz = H + 2 * TQP;
+                for (int i = tid; i < W; i += 256) { X[i] = (T)pr[i - (TQP - 1)]; X[W + i] = (T)pi[i - (TQP - 1)]; }
+                for (int i = tid; i < TQP; i += 256) { H[i] = fi[i]; H[TQP + i] = fq[i]; }
+                __syncthreads();
+                for (int o = tid; o < 2 * st.n_in; o += 256) {
+                    const int pl = o / st.n_in, j = o - pl * st.n_in;
+                    const T *__restrict__ x = X + pl * W + (TQP - 1) + j;
+                    const T *__restrict__ h = H + pl * TQP;
+                    T acc = T(0);
+#pragma unroll 8
+                    for (int q = 0; q < TQP; q++) acc = fma(x[-q], h[q], acc);
+                    Rz[pl * st.n_in + j] = acc;
+                }
+                __syncthreads();
+                for (int j = tid; j < st.n_in; j += 256) {
+                    const T ar = Rz[j], ai = Rz[st.n_in + j];
+                    if (st.sub == 0) o0[j] = (double)(lower ? ar + ai : ar - ai);
+                    else if (st.sub == 1) o0[j] = hypot((double)ar, (double)ai);
+                    else { o0[j] = (double)ar; sv_ptr(st.out, rx, 1)[j] = (double)ai; }
+                }
+                break;
+            }
             for (int j = tid; j < st.n_in; j += 256) {
                 T ar, ai;
                 if (N == 0) { ar = (T)pr[j]; ai = (T)pi[j]; }
