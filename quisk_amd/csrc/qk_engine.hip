@@ -2172,7 +2172,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     }
     {
         hipEvent_t evf = (e->pipe_blocks & 1) ? e->ev_fe2 : e->ev_fe;
-        HIPCHECK(hipEventRecord(evf, e->fe_stream));
+        if (!e->small_mode) HIPCHECK(hipEventRecord(evf, e->fe_stream));     // (short blocks: one stream, the order is the stream's own)
         HIPCHECK(hipStreamWaitEvent(e->stream, evf, 0));
     }
     // ---- remaining integer decimation, all receivers ----
@@ -2213,7 +2213,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         }
     }
     if (lane_used[1] || lane_used[2]) {
-        HIPCHECK(hipEventRecord(e->ev_front, e->stream));
+        if (!e->small_mode) HIPCHECK(hipEventRecord(e->ev_front, e->stream));
         for (int k = 1; k < 3; k++) if (lane_used[k]) HIPCHECK(hipStreamWaitEvent(lanes[k], e->ev_front, 0));
     }
     for (int cl = 0; cl < CL_COUNT; cl++) {
@@ -2237,7 +2237,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         // the other lanes join: the AGC, the tail copies and the next block's decimators (which overwrite what these
         // chains read) all come behind them
         if (!lane_used[k]) continue;
-        HIPCHECK(hipEventRecord(e->ev_lane[k - 1], lanes[k]));
+        if (!e->small_mode) HIPCHECK(hipEventRecord(e->ev_lane[k - 1], lanes[k]));
         HIPCHECK(hipStreamWaitEvent(e->stream, e->ev_lane[k - 1], 0));
     }
     // ---- stereo routes: the two detected streams, count-equalised, become one pair that runs its own tail chain ----
@@ -2264,10 +2264,10 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         if (t.n_out > (int)e->out_stride) return fail(QK_ERANGE, "internal: audio block exceeds the output stride");
         e->out_count[r.rx] = t.n_out;
     }
-    HIPCHECK(hipEventRecord(e->ev_chain, e->stream));
+    if (!e->small_mode) HIPCHECK(hipEventRecord(e->ev_chain, e->stream));
     HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_chain, 0));
     if (fe_writes) {
-        HIPCHECK(hipEventRecord(e->ev_read[q], e->stream));
+        if (!e->small_mode) HIPCHECK(hipEventRecord(e->ev_read[q], e->stream));
         e->read_pending[q] = true;
         e->fe_blocks++;
     }
@@ -2370,7 +2370,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         int rco = output_stage(e, agc_ev_stream);
         if (rco != QK_OK) return rco;
     }
-    HIPCHECK(hipEventRecord(e->ev_agc[par], agc_ev_stream));
+    if (!e->small_mode) HIPCHECK(hipEventRecord(e->ev_agc[par], agc_ev_stream));
     // ---- carry stream tails ----
     {
         // (short blocks: the front chain's and the classes' tails leave in ONE launch, each entry with its own receiver list)
