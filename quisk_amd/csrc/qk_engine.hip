@@ -151,6 +151,10 @@ struct qk_engine {
     hipEvent_t ev_chain = nullptr, ev_agc[2] = {nullptr, nullptr};
     hipEvent_t ev_front = nullptr, ev_lane[2] = {nullptr, nullptr};      // fork / join of the second lane of class chains
     hipEvent_t ev_fe = nullptr, ev_fe2 = nullptr;      // front end (and head copy) of this block done (alternating)
+    double2 *d_in_alt = nullptr; hipEvent_t ev_in[2] = {nullptr, nullptr}; bool in_used[2] = {false, false}; int in_slot = 0;   // short blocks: two
+                                                            // pinned input blocks, so that a call does not wait for the previous block's last readers
+    hipEvent_t ev_audio = nullptr; bool audio_ev = false;   // short blocks: recorded behind the kernels that write the audio rows (qk_pull_audio* wait for it,
+                                                            // not for the tail copies and the spectrum's frames enqueued behind it)
     hipEvent_t ev_read[2] = {nullptr, nullptr};        // the chains have finished reading front-stream twin q
     bool read_pending[2] = {false, false};
     int fe_blocks = 0;                                 // blocks in which the front end produced output (twin parity)
@@ -1079,6 +1083,7 @@ static int engine_init(qk_engine *e)
         }
         HIPCHECK(hipStreamCreateWithFlags(&e->fe_stream, hipStreamNonBlocking));
     }
+    HIPCHECK(hipEventCreateWithFlags(&e->ev_audio, sync_event_flags()));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_fe, sync_event_flags()));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_fe2, sync_event_flags()));
     HIPCHECK(hipEventCreateWithFlags(&e->ev_read[0], sync_event_flags()));
@@ -1127,6 +1132,10 @@ static int engine_init(qk_engine *e)
         HIPCHECK(hipMemcpy(e->d_tw4096, tw.data(), sizeof(double2) * 4096, hipMemcpyHostToDevice));
     }
     if (e->small_mode) HIPCHECK(hipHostMalloc(&e->d_in, (size_t)std::max(cfg.max_block, 1) * sizeof(double2), hipHostMallocDefault));
+    if (e->small_mode) {
+        HIPCHECK(hipHostMalloc(&e->d_in_alt, (size_t)std::max(cfg.max_block, 1) * sizeof(double2), hipHostMallocDefault));
+        for (auto &ev : e->ev_in) HIPCHECK(hipEventCreateWithFlags(&ev, sync_event_flags()));
+    }
     else HIPCHECK(hipMalloc(&e->d_in, (size_t)cfg.max_block * sizeof(double2)));
     {
         const int nseg = (cfg.max_block + DC_SEG - 1) / DC_SEG;
@@ -2085,7 +2094,9 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     Timer block_timer(e, 8);
     x = condition_input(e, x, n);
     // ---- display spectrum: frames of the samples as they arrive, before the mixer (quisk.c:2324-2348) ----
-    if (e->fftN > 0) { int rcs = feed_spectrum(e, x, n); if (rcs != QK_OK) return rcs; }
+    // (short blocks: the spectrum's frames are enqueued behind the audio path, off the way of qk_pull_audio)
+    const bool spectrum_last = e->small_mode && e->nrx > 0;
+    if (e->fftN > 0 && !spectrum_last) { int rcs = feed_spectrum(e, x, n); if (rcs != QK_OK) return rcs; }
     if (e->nrx == 0) {
         HIPCHECK(hipGetLastError());
         e->stats.samples_in += n;
@@ -2371,6 +2382,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         if (rco != QK_OK) return rco;
     }
     if (!e->small_mode) HIPCHECK(hipEventRecord(e->ev_agc[par], agc_ev_stream));
+    else { HIPCHECK(hipEventRecord(e->ev_audio, e->stream)); e->audio_ev = true; }
     // ---- carry stream tails ----
     {
         // (short blocks: the front chain's and the classes' tails leave in ONE launch, each entry with its own receiver list)
@@ -2440,6 +2452,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         }
         e->agc_pending = true;
     }
+    if (e->fftN > 0 && spectrum_last) { int rcs = feed_spectrum(e, x, n); if (rcs != QK_OK) return rcs; }
     HIPCHECK(hipGetLastError());
     e->stats.samples_in += n;
     e->stats.blocks += 1;
@@ -2499,7 +2512,8 @@ void qk_destroy(qk_engine *e)
                     (void *)e->d_bs_out, (void *)e->d_bs_X, (void *)e->d_bs_max})
         if (p) hipFree(p);
     for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
-    if (e->small_mode) { if (e->d_in) hipHostFree(e->d_in); if (e->d_out) hipHostFree(e->d_out); e->d_in = nullptr; e->d_out = nullptr; }
+    if (e->small_mode) { if (e->d_in) hipHostFree(e->d_in); if (e->d_in_alt) hipHostFree(e->d_in_alt); if (e->d_out) hipHostFree(e->d_out); e->d_in = nullptr; e->d_out = nullptr; }
+    for (auto &ev : e->ev_in) if (ev) hipEventDestroy(ev);
     void *ptrs[] = {e->d_nb_x[0], e->d_nb_x[1], e->d_nb_mag[0], e->d_nb_mag[1], e->d_nb_p[0], e->d_nb_p[1], e->d_nb_y, e->d_nb_loc, e->d_nb_segsum,
                     e->d_nb_segbase, e->d_nb_S, e->d_nb_words, e->d_nb_any, e->d_cond, e->d_dc_seg_end, e->d_dc_seg_in, e->d_dc_state, e->d_dc_partial, e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps, e->d_cls,
                     e->d_mode, e->d_release_gain, e->d_coefs_f, e->d_taps_f, e->d_agc, e->d_agc_started, e->d_gains, e->d_agc_mag, e->d_sq_state, e->d_sq_partial, e->d_sq_flag, e->d_out,
@@ -2537,6 +2551,7 @@ void qk_destroy(qk_engine *e)
     if (e->ev_front) hipEventDestroy(e->ev_front);
     for (auto &ev : e->ev_lane) if (ev) hipEventDestroy(ev);
     for (auto &ev : e->ev_agc) if (ev) hipEventDestroy(ev);
+    if (e->ev_audio) hipEventDestroy(e->ev_audio);
     if (e->ev_fe) hipEventDestroy(e->ev_fe);
     if (e->ev_fe2) hipEventDestroy(e->ev_fe2);
     for (auto &ev : e->ev_read) if (ev) hipEventDestroy(ev);
@@ -2749,10 +2764,21 @@ int qk_process_samples(qk_engine *e, const double *iq_host, int n)
     ENGINE_ENTER(e);
     if (n < 0 || n > e->cfg.max_block) return fail(QK_ERANGE, "block larger than max_block");
     if (!iq_host && n > 0) return fail(QK_EINVAL, "null sample pointer");
+    if (n > 0 && e->small_mode) {
+        // two pinned input blocks in turn: this one was last read by the block before last (its event: long past), so the call
+        // does not wait for the previous block's tail copies and spectrum frames
+        const int sl = e->in_slot ^= 1;
+        double2 *dst = sl ? e->d_in_alt : e->d_in;
+        if (e->in_used[sl]) HIPCHECK(hipEventSynchronize(e->ev_in[sl]));
+        memcpy(dst, iq_host, (size_t)n * sizeof(double2));      // (pinned: the kernels read it over the bus)
+        const int rc = process_device(e, dst, n);
+        if (rc == QK_OK) { HIPCHECK(hipEventRecord(e->ev_in[sl], e->stream)); e->in_used[sl] = true; }
+        else SYNC_ALL(e);
+        return rc;
+    }
     if (n > 0) {
         SYNC_ALL(e);      // the previous block may still read d_in
-        if (e->small_mode) memcpy(e->d_in, iq_host, (size_t)n * sizeof(double2));      // (pinned: the kernels read it over the bus)
-        else HIPCHECK(hipMemcpyAsync(e->d_in, iq_host, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, e->fe_stream));
+        HIPCHECK(hipMemcpyAsync(e->d_in, iq_host, (size_t)n * sizeof(double2), hipMemcpyHostToDevice, e->fe_stream));
     }
     return process_device(e, e->d_in, n);
 }
@@ -2799,7 +2825,7 @@ int qk_pull_audio(qk_engine *e, int rx, double *dst, int cap)
     const int m = std::min(e->out_count[rx], cap);
     if (m > 0 && !dst) return fail(QK_EINVAL, "null destination");
     if (e->small_mode) {
-        SYNC_ALL(e);
+        if (e->audio_ev) HIPCHECK(hipEventSynchronize(e->ev_audio)); else SYNC_ALL(e);
         if (m > 0) memcpy(dst, e->d_out + (size_t)rx * e->out_stride, (size_t)m * sizeof(double2));     // (the rows are host memory)
         AGC_ABORT_CHECK(e);
         return m;
@@ -2827,7 +2853,7 @@ int qk_pull_audio_all(qk_engine *e, double *dst, size_t stride, int *counts)
         counts[r] = m;
     }
     if (e->small_mode) {
-        SYNC_ALL(e);
+        if (e->audio_ev) HIPCHECK(hipEventSynchronize(e->ev_audio)); else SYNC_ALL(e);
         for (int r = 0; r < e->nrx; r++)
             memcpy(dst + 2 * (size_t)r * stride, e->d_out + (size_t)r * e->out_stride, std::min(stride, e->out_stride) * sizeof(double2));
         AGC_ABORT_CHECK(e);
