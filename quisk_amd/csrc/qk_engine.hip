@@ -151,6 +151,7 @@ struct qk_engine {
     hipEvent_t ev_chain = nullptr, ev_agc[2] = {nullptr, nullptr};
     hipEvent_t ev_front = nullptr, ev_lane[2] = {nullptr, nullptr};      // fork / join of the second lane of class chains
     hipEvent_t ev_fe = nullptr, ev_fe2 = nullptr;      // front end (and head copy) of this block done (alternating)
+    bool in_on_device = false;
     double2 *d_in_alt = nullptr; hipEvent_t ev_in[2] = {nullptr, nullptr}; bool in_used[2] = {false, false}; int in_slot = 0;   // short blocks: two
                                                             // pinned input blocks, so that a call does not wait for the previous block's last readers
     hipEvent_t ev_audio = nullptr; bool audio_ev = false;   // short blocks: recorded behind the kernels that write the audio rows (qk_pull_audio* wait for it,
@@ -1131,9 +1132,22 @@ static int engine_init(qk_engine *e)
         HIPCHECK(hipMalloc(&e->d_tw4096, sizeof(double2) * 4096));
         HIPCHECK(hipMemcpy(e->d_tw4096, tw.data(), sizeof(double2) * 4096, hipMemcpyHostToDevice));
     }
-    if (e->small_mode) HIPCHECK(hipHostMalloc(&e->d_in, (size_t)std::max(cfg.max_block, 1) * sizeof(double2), hipHostMallocDefault));
     if (e->small_mode) {
-        HIPCHECK(hipHostMalloc(&e->d_in_alt, (size_t)std::max(cfg.max_block, 1) * sizeof(double2), hipHostMallocDefault));
+        // the two input blocks: fine-grained DEVICE memory the host stores into directly over the bus (large BAR; 0.5 us per
+        // 960-sample block, write-combined) -- the front end then reads local memory; where the platform refuses that, pinned
+        // host memory the kernels read over the bus (the front end's launch is 8 us longer)
+        const size_t ib = (size_t)std::max(cfg.max_block, 1) * sizeof(double2);
+        int large_bar = 0;          // (the whole of device memory is mapped for the host only with a large BAR)
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, cfg.device) != hipSuccess) large_bar = 0;
+        e->in_on_device = large_bar && hipExtMallocWithFlags((void **)&e->d_in, ib, hipDeviceMallocFinegrained) == hipSuccess &&
+                          hipExtMallocWithFlags((void **)&e->d_in_alt, ib, hipDeviceMallocFinegrained) == hipSuccess;
+        if (const char *v = getenv("QK_IN_ON_DEVICE")) if (!atoi(v) && e->in_on_device) { hipFree(e->d_in); hipFree(e->d_in_alt); e->d_in = e->d_in_alt = nullptr; e->in_on_device = false; }
+        if (!e->in_on_device) {
+            (void)hipGetLastError();
+            if (e->d_in) { hipFree(e->d_in); e->d_in = nullptr; }
+            HIPCHECK(hipHostMalloc(&e->d_in, ib, hipHostMallocDefault));
+            HIPCHECK(hipHostMalloc(&e->d_in_alt, ib, hipHostMallocDefault));
+        }
         for (auto &ev : e->ev_in) HIPCHECK(hipEventCreateWithFlags(&ev, sync_event_flags()));
     }
     else HIPCHECK(hipMalloc(&e->d_in, (size_t)cfg.max_block * sizeof(double2)));
@@ -2512,7 +2526,12 @@ void qk_destroy(qk_engine *e)
                     (void *)e->d_bs_out, (void *)e->d_bs_X, (void *)e->d_bs_max})
         if (p) hipFree(p);
     for (int i = 0; i < 2; i++) { if (e->d_mixhist[i]) hipFree(e->d_mixhist[i]); if (e->d_v0[i]) hipFree(e->d_v0[i]); }
-    if (e->small_mode) { if (e->d_in) hipHostFree(e->d_in); if (e->d_in_alt) hipHostFree(e->d_in_alt); if (e->d_out) hipHostFree(e->d_out); e->d_in = nullptr; e->d_out = nullptr; }
+    if (e->small_mode) {
+        if (e->in_on_device) { if (e->d_in) hipFree(e->d_in); if (e->d_in_alt) hipFree(e->d_in_alt); }
+        else { if (e->d_in) hipHostFree(e->d_in); if (e->d_in_alt) hipHostFree(e->d_in_alt); }
+        if (e->d_out) hipHostFree(e->d_out);
+        e->d_in = nullptr; e->d_out = nullptr;
+    }
     for (auto &ev : e->ev_in) if (ev) hipEventDestroy(ev);
     void *ptrs[] = {e->d_nb_x[0], e->d_nb_x[1], e->d_nb_mag[0], e->d_nb_mag[1], e->d_nb_p[0], e->d_nb_p[1], e->d_nb_y, e->d_nb_loc, e->d_nb_segsum,
                     e->d_nb_segbase, e->d_nb_S, e->d_nb_words, e->d_nb_any, e->d_cond, e->d_dc_seg_end, e->d_dc_seg_in, e->d_dc_state, e->d_dc_partial, e->d_tabA, e->d_tabB, e->d_tabC, e->d_mix_on, e->d_in, e->d_raw, e->d_coefs, e->d_taps, e->d_ntaps, e->d_cls,
@@ -2770,7 +2789,8 @@ int qk_process_samples(qk_engine *e, const double *iq_host, int n)
         const int sl = e->in_slot ^= 1;
         double2 *dst = sl ? e->d_in_alt : e->d_in;
         if (e->in_used[sl]) HIPCHECK(hipEventSynchronize(e->ev_in[sl]));
-        memcpy(dst, iq_host, (size_t)n * sizeof(double2));      // (pinned: the kernels read it over the bus)
+        memcpy(dst, iq_host, (size_t)n * sizeof(double2));
+        __builtin_ia32_sfence();             // (write-combined stores leave the core before the launch's doorbell)
         const int rc = process_device(e, dst, n);
         if (rc == QK_OK) { HIPCHECK(hipEventRecord(e->ev_in[sl], e->stream)); e->in_used[sl] = true; }
         else SYNC_ALL(e);
