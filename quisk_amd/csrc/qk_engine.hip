@@ -2328,6 +2328,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             // (short blocks are bound by the host's launches, and the second stream costs two more calls: it is used from
             // 4096 audio samples per receiver on)
             const bool own = e->apply_stream && m_max >= 4096;
+            a.apply_here = (e->small_mode && !own) ? 1 : 0;
             // The gain pass sets the block period at low sample rates and runs back to back on this stream: the event the
             // apply stream waits for rides on the kernel's own completion signal (hipExtLaunchKernelGGL) instead of a
             // marker packet of its own behind it.
@@ -2345,7 +2346,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
                 aps = e->apply_stream;
                 a.started = e->d_agc_started2;
             }
-            hipLaunchKernelGGL(k_agc_apply, grid1(m_max, 1, e->nrx), dim3(256), 0, aps, a);
+            if (!a.apply_here) hipLaunchKernelGGL(k_agc_apply, grid1(m_max, 1, e->nrx), dim3(256), 0, aps, a);
             for (int cl = 0; cl < CL_COUNT; cl++) {
                 if (a.n_c[cl] <= 0) continue;
                 for (int r : e->cls_chain[cl].members)

@@ -1288,6 +1288,7 @@ struct AgcArgs {
     const int *started;        // [rx] 0 until the receiver's first call: the reference then only initialises
                                // and returns the block untouched (quisk.c:2033-2050)
     int *abort_flag;           // host-visible word, set when a hand-over of k_agc_gain timed out (the gains are then NaN)
+    int apply_here;            // short blocks: k_agc_gain applies the gains itself behind its last tile (no k_agc_apply launch)
 };
 
 // cabs for the complex AGC.  The reference's cabs is the C library's hypot; the oracle runs against glibc 2.35, whose
@@ -1521,6 +1522,7 @@ __device__ __forceinline__ double agc_chain_bin(const double g0, const double ke
     return gv;
 }
 
+__device__ __forceinline__ void agc_apply_one(const AgcArgs &a, const int rx, const int i);
 __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
 {
 #pragma clang fp contract(off)
@@ -1540,7 +1542,10 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
     const int rx = blockIdx.x;
     const int cl = a.cls[rx];
     const int n_new = a.n_c[cl];
-    if (!a.started[rx] || n_new <= 0) return;       // (the whole workgroup)
+    if (!a.started[rx] || n_new <= 0) {             // (the whole workgroup)
+        if (a.apply_here) for (int i = threadIdx.x; i < n_new; i += 192) agc_apply_one(a, rx, i);    // (a first block goes out untouched)
+        return;
+    }
     if (threadIdx.x < AGC_RING) ring[threadIdx.x].rec.tag = -1;
     if (threadIdx.x == 0) { wstat = 0; fetched = 0; aborted = 0; }
     __syncthreads();
@@ -1967,6 +1972,12 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
             if (ch + 1 < nch) load_chunk(ch + 1);   // in flight while the walker works through chunk ch
         }
     }
+    if (a.apply_here) {
+        // short blocks: the gains are all there once the walker is through -- the workgroup applies them itself (k_agc_apply's
+        // operation per sample) instead of a launch behind this one
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_new; i += 192) agc_apply_one(a, rx, i);
+    }
 }
 // magnitudes of the complex classes' new samples, for k_agc_gain (grid: samples, 1, receivers)
 __global__ __launch_bounds__(256) void k_agc_cabs(AgcArgs a)
@@ -1977,11 +1988,9 @@ __global__ __launch_bounds__(256) void k_agc_cabs(AgcArgs a)
     if (!a.cpx_c[cl] || i >= a.n_c[cl]) return;
     sv_ptr(a.mag_c[cl], rx, 0)[i] = cabs_cr(sv_ptr(a.in_c[cl], rx, 0)[i], sv_ptr(a.in_c[cl], rx, 1)[i]);
 }
-__global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
+__device__ __forceinline__ void agc_apply_one(const AgcArgs &a, const int rx, const int i)
 {
 #pragma clang fp contract(off)
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int rx = blockIdx.z;
     const int cl = a.cls[rx];
     if (i >= a.n_c[cl]) return;
     const double *p = sv_ptr(a.in_c[cl], rx, 0) + i;
@@ -2010,6 +2019,10 @@ __global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
     }
     if (a.kill || (a.mute && a.mute[rx])) d = 0.0;      // silence behind the AGC, whose state moves on
     a.out[(long long)rx * a.out_stride + i] = make_double2(d, d);
+}
+__global__ __launch_bounds__(256) void k_agc_apply(AgcArgs a)
+{
+    agc_apply_one(a, blockIdx.z, blockIdx.x * 256 + threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
