@@ -363,7 +363,7 @@ def config1_leg(local, with_cpu):
     eng.close()
     res = {"workload": "BASELINE configs[0]: 1 USB receiver, 192 ksps, 960-sample host blocks, audio pulled every block, 4096-point graph",
            "msamples_per_s": blk * nblk / dt / 1e6, "realtime_factor": blk * nblk / dt / fs, "ms_per_block": dt / nblk * 1e3,
-           "fft_frames": frames, "note": "launch-bound: one 5 ms block is ~25 kernel launches and two synchronisations"}
+           "fft_frames": frames, "note": "short-block mode (max_block <= 4096): one stream, front end -> one fused chain launch -> AGC gain + apply in one launch; input written by the host into device memory, audio rows in pinned host memory; tail copies and spectrum frames behind the audio event"}
     if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import _bind as B

@@ -138,7 +138,8 @@ int qk_pull_audio(qk_engine *e, int rx, double *dst_host, int cap);
 /* All receivers at once: dst is [n_receivers][stride] complex samples; counts[n_receivers]. */
 int qk_pull_audio_all(qk_engine *e, double *dst_host, size_t stride, int *counts);
 /* Device pointer and stride (in complex samples) of the audio output array, for zero-copy consumers
- * and for the RCCL gather. */
+ * and for the RCCL gather.  With max_block <= 4096 (the short-block mode: one stream, one fused chain launch, see DESIGN.md
+ * section 4) the rows live in pinned host memory that the device addresses through the same pointer. */
 int qk_audio_device(qk_engine *e, const double **dev_ptr, size_t *stride);
 /* Device-to-device copy of the last block's audio into a caller-owned device buffer
  * [n_receivers][dst_stride] complex samples (e.g. the send buffer of an RCCL gather). */

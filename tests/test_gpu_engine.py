@@ -314,25 +314,41 @@ def test_three_fifths_and_the_resampler(fs, sizes):
     assert differs
 
 
-@pytest.mark.parametrize("fs,blk,mode,play", [(192000, 960, 3, 48000), (250000, 5000, 5, 96000), (1536000, 16384, 4, 48000)])
-def test_fused_chain_is_the_separate_kernels(fs, blk, mode, play, monkeypatch):
-    """QK_FUSE=1 (a short block's class chain as one launch, k_chain_fused; off by default) makes the
-    audio of the separate kernels bit for bit: same arithmetic, same order, one workgroup per receiver."""
-    import os
+@pytest.mark.parametrize("fs,blk,modes,play", [(192000, 960, [3], 48000), (250000, 5000, [5], 96000), (1536000, 16384, [4], 48000),
+                                               (192000, 960, [3, 2], 48000), (192000, 777, [3, 5, 4], 48000)])
+def test_short_block_mode_is_the_pipelined_mode(fs, blk, modes, play, monkeypatch):
+    """The short-block mode (max_block <= 4096 or QK_SMALL_MODE=1: one stream, the front chain's FIRs and the class chain as one
+    fused launch -- k_chain_fused --, the AGC applying its own gains, input stored by the host into device memory, audio rows in
+    pinned host memory) makes the audio of the four-stream pipeline with its separate kernels bit for bit:
+    same arithmetic in the same order.  Variants: pipelined; short-block without fusion; short-block with fusion (one class with
+    every receiver: the front chain rides along; several classes: each chain fused on its own)."""
     from quisk_amd import Engine, rx_filter
     from quisk_amd.synth import make_iq
-    x = make_iq(blk * 12, fs, [fs // 10], [mode], 77)
+    nb = 12
+    tunes = [fs // 10 + 3000 * i for i in range(len(modes))]
+    x = make_iq(blk * nb, fs, tunes, modes, 77)
     outs = []
-    for fuse in ("0", "1"):
+    for small, fuse in (("0", "0"), ("1", "0"), ("1", "1")):
+        monkeypatch.setenv("QK_SMALL_MODE", small)
         monkeypatch.setenv("QK_FUSE", fuse)
-        eng = Engine(fs, n_receivers=1, max_block=blk, playback_rate=play)
-        fi, fq, bw, off = rx_filter(fs, mode)
-        eng.set_mode(0, mode); eng.set_tune(0, fs // 10); eng.set_filters(0, fi, fq, bw, off)
-        got = []
-        for i in range(12):
+        eng = Engine(fs, n_receivers=len(modes), playback_rate=play, max_block=blk, fft_size=1024, data_width=512)
+        for r, m in enumerate(modes):
+            fi, fq, bw, off = rx_filter(fs, m)
+            eng.set_mode(r, m); eng.set_tune(r, tunes[r]); eng.set_filters(r, fi, fq, bw, off)
+        got = [[] for _ in modes]
+        rows = []
+        for i in range(nb):
             eng.process(x[i * blk:(i + 1) * blk])
-            got.append(eng.audio(0))
+            for r in range(len(modes)):
+                got[r].append(eng.audio(r))
+            if i % 4 == 3:
+                cnt, row, _ = eng.get_graph(1.0, 0.0)
+                rows.append(row.copy() if cnt else np.zeros_like(row))
         eng.close()
-        outs.append(np.concatenate(got))
-    assert outs[0].size == outs[1].size and outs[0].size > 0
-    assert np.array_equal(outs[0].view(np.float64).view(np.uint64), outs[1].view(np.float64).view(np.uint64))
+        outs.append((np.concatenate([np.concatenate(g) for g in got]), np.concatenate(rows)))
+    ref_a, ref_g = outs[0]
+    assert ref_a.size > 0 and np.any(ref_a != 0)
+    for a, g in outs[1:]:
+        assert a.size == ref_a.size
+        assert np.array_equal(a.view(np.float64).view(np.uint64), ref_a.view(np.float64).view(np.uint64))
+        assert np.array_equal(g.view(np.uint64), ref_g.view(np.uint64))       # the spectrum rows too (frames enqueued behind the audio)
