@@ -41,7 +41,10 @@ typedef struct qk_config {
                               direct transform) or 0 for no spectrum (record_app, quisk.c:5054) */
     int data_width;        /* graph points returned by qk_get_graph (record_app, quisk.c:5054) */
     int reserved[8];       /* [0] = largest receive-filter length accepted by qk_set_filters (0 = 1024);
-                              [1] = 1: fp32 mode (BASELINE configs[4]; the reference computes in double); rest zero */
+                              [1] = 1: fp32 mode (BASELINE configs[4]; the reference computes in double);
+                              [2] = short-block mode (one stream, fused chain launch, host-resident audio rows: for polls of a
+                                    few thousand samples, the reference's own operating point): 0 = when max_block <= 4096,
+                                    1 = on, 2 = off; rest zero */
 } qk_config;
 
 /* record_app (quisk.c:5048-5113): allocates the FFT buffers/window and initialises every filter state

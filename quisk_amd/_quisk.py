@@ -103,7 +103,8 @@ def record_app(app, conf, data_width, graph_width, fft_size, multirx_data_width,
         s.eng = _eng.Engine(s.rate, n_receivers=nrx + 1, playback_rate=int(getattr(conf, "playback_rate", 48000)),
                             max_block=SAMP_BUFFER_SIZE, fft_size=s.fft_size, data_width=s.data_width,
                             device=int(getattr(conf, "quisk_amd_device", 0)),
-                            max_filter_taps=int(getattr(conf, "quisk_amd_max_filter_taps", 0)))
+                            max_filter_taps=int(getattr(conf, "quisk_amd_max_filter_taps", 0)),
+                            short_blocks=bool(int(getattr(conf, "quisk_amd_short_blocks", 1 if s.rate <= 384000 else 0))))
     except Exception as exc:                          # no GPU, bad sizes ...: the module's own exception type
         raise error(str(exc))
     rel = getattr(conf, "agc_release_time", None)

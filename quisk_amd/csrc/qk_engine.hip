@@ -1067,7 +1067,7 @@ static int engine_init(qk_engine *e)
 {
     const qk_config &cfg = e->cfg;
     HIPCHECK(hipSetDevice(cfg.device));
-    e->small_mode = cfg.max_block <= 4096;
+    e->small_mode = cfg.reserved[2] == 1 || (cfg.reserved[2] == 0 && cfg.max_block <= 4096);
     if (const char *v = getenv("QK_SMALL_MODE")) e->small_mode = atoi(v) != 0;
     HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     if (e->small_mode) {
@@ -2499,6 +2499,7 @@ int qk_create(qk_engine **out, const qk_config *cfg)
         return fail(QK_EHIP, "no HIP device: the engine has no CPU path");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(QK_EINVAL, "bad device ordinal");
     if (cfg->reserved[1] != 0 && cfg->reserved[1] != 1) return fail(QK_EINVAL, "qk_config.reserved[1]: 0 = fp64, 1 = fp32 mode");
+    if (cfg->reserved[2] < 0 || cfg->reserved[2] > 2) return fail(QK_EINVAL, "qk_config.reserved[2]: short-block mode 0 = by max_block, 1 = on, 2 = off");
     qk_engine *e = new (std::nothrow) qk_engine();
     if (!e) return fail(QK_ENOMEM, "out of host memory");
     e->cfg = *cfg;

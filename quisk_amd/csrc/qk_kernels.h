@@ -1903,7 +1903,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                     agc_take(lds_addr(&ring[slot].rec), lds_addr(&ring[slot].gv[lane]),
                              lds_addr(&sm[(k / AGC_CHUNK) & 1][(k % AGC_CHUNK) * 64 + lane]), tagv, r0, r1, gvv, mv);
                     if (uni(tagv) != (int)(tag_of(gen, k) | 0x80000000)) break;         // not there yet, or not a plain tile
-                    const bool quiet = (unid(r0.y) == cur_add) & (readlane_f64(gvv, 0) == s.gain) & !(mv * gvv > c.ceil_);
+                    const bool quiet = ((int)(unid(r0.y) == cur_add) & (int)(readlane_f64(gvv, 0) == s.gain) & (int)!(mv * gvv > c.ceil_)) != 0;
                     if (__ballot(quiet) != ~0ull) break;
                     unsigned long long over = __ballot(mv > s.themax);
                     while (over) {

@@ -231,6 +231,8 @@ static PyObject *record_app(PyObject *self, PyObject *args)
     cfg.fft_size = fft; cfg.data_width = dw;
     cfg.reserved[0] = QuiskGetConfigInt("quisk_amd_max_filter_taps", 0);
     cfg.reserved[1] = QuiskGetConfigInt("quisk_amd_fp32", 0);
+    /* polls of 5 ms (data_poll_usec) are a few thousand samples up to a few hundred ksps: the engine's short-block mode */
+    cfg.reserved[2] = QuiskGetConfigInt("quisk_amd_short_blocks", rate <= 384000 ? 1 : 2);
     if (qk_create(&G.qk, &cfg) != QK_OK) { G.qk = NULL; Py_CLEAR(G.app); Py_CLEAR(G.conf); return engine_error(); }
     const double rel = QuiskGetConfigDouble("agc_release_time", 1.0);          /* quisk.c:3833 */
     if (rel > 0) qk_set_agc_release_time(G.qk, rel);

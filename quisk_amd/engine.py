@@ -141,12 +141,13 @@ class Engine:
     """N receivers on one wideband I/Q stream (the reference's quisk_process_samples, batched)."""
 
     def __init__(self, sample_rate, n_receivers=1, playback_rate=48000, max_block=66000, fft_size=0,
-                 data_width=0, device=0, max_filter_taps=0, fp32=False):
+                 data_width=0, device=0, max_filter_taps=0, fp32=False, short_blocks=None):
         self.L = lib()
         cfg = QkConfig(device=device, sample_rate=sample_rate, playback_rate=playback_rate,
                        n_receivers=n_receivers, max_block=max_block, fft_size=fft_size, data_width=data_width)
         cfg.reserved[0] = max_filter_taps
         cfg.reserved[1] = 1 if fp32 else 0          # optional fp32 mode (BASELINE configs[4]); fp64 is the reference's arithmetic
+        cfg.reserved[2] = 0 if short_blocks is None else (1 if short_blocks else 2)   # short-block mode: None = when max_block <= 4096
         self.fp32 = bool(fp32)
         self.h = C.c_void_p()
         _check(self.L.qk_create(C.byref(self.h), C.byref(cfg)))
