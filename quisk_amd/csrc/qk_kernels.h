@@ -1547,7 +1547,9 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
         return;
     }
     if (threadIdx.x < AGC_RING) ring[threadIdx.x].rec.tag = -1;
-    if (threadIdx.x == 0) { wstat = 0; fetched = 0; aborted = 0; }
+    // (agc_tight_run makes slot addresses by OR-ing a masked count into the ring's base: a ring that the compiler did not put on
+    // a 16 KiB boundary must not go unnoticed -- the block is then poisoned like a timed-out hand-over)
+    if (threadIdx.x == 0) { wstat = 0; fetched = 0; aborted = ((unsigned)reinterpret_cast<size_t>(&ring[0]) & 0x3fffu) ? 1 : 0; }
     __syncthreads();
     __builtin_amdgcn_s_setprio(3);      // latency-bound waves among the front end's throughput-bound ones: issue first
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1746,7 +1748,8 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
     } else if (wave == 1) {
         // ---------------- the walker ----------------
         int gen = 0;
-        int dead = 0;                               // (read through uni(): the tests on it are wave-uniform branches)
+        int dead = uni(peek(&aborted));             // (read through uni(): the tests on it are wave-uniform branches; set from the start
+                                                    // by the ring-alignment check above)
 #ifdef AGC_PROF
         long long wp_wait = 0, wp_waited = 0, wp_take = 0; const long long wp_t0 = clock64();
 #endif
