@@ -1422,7 +1422,9 @@ struct __attribute__((aligned(1024))) AgcRingSlot { double gv[64]; AgcSlot rec; 
 // ifs, no early exits): a taken branch costs this single wave some twenty cycles, and the compiler's loop-exit
 // unification turns `continue` / `return` into many of them.
 #define AGC_RING 16
+#ifndef AGC_CHUNK
 #define AGC_CHUNK 32
+#endif
 #define AGC_SPIN_LIMIT (1 << 22)
 #define AGC_LDS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // a 32-bit LDS store from lane 0 alone, without a branch the compiler can see
