@@ -1971,9 +1971,11 @@ static void launch_frontend(qk_engine *e, const FrontArgs &fa, int nspans)
     // every CU's LDS and registers to the kernels of the other two streams
     int gx = nspans;
     if (e->fe_share < 100) gx = std::max(1, std::min(nspans, (int)((long long)e->fe_slots * e->fe_share / 100 / std::max(1, e->nrx))));
-    if (e->fp32 && e->fe_packed) hipLaunchKernelGGL((k_frontend_pk<S>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
-    else if (e->fp32) hipLaunchKernelGGL((k_frontend_wave<S, float>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
-    else hipLaunchKernelGGL((k_frontend_wave<S, double>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fa);
+    FrontArgs fb = fa;
+    if (gx <= 2 && (fa.hist_out || fa.head_src)) { fb.helpers = 2; gx += 2; }      // (a span walk of one or two workgroups: the copies get their own)
+    if (e->fp32 && e->fe_packed) hipLaunchKernelGGL((k_frontend_pk<S>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fb);
+    else if (e->fp32) hipLaunchKernelGGL((k_frontend_wave<S, float>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fb);
+    else hipLaunchKernelGGL((k_frontend_wave<S, double>), dim3(gx, e->nrx), dim3(64), 0, e->fe_stream, fb);
 }
 
 // NoiseBlanker (quisk.c:2322): five launches on the front end's stream

@@ -115,6 +115,8 @@ struct FrontArgs {
     double2 *hist_out;         // the front-end kernels also leave the next block's history and tune vector (what k_mixhist_update
     double2 *v0_next;          // does; null: a launch of that kernel follows)
     int out_f32;               // k_frontend_pk: the output stream holds floats (its readers are the float FIRs)
+    int helpers;               // short blocks: the last `helpers` workgroups of a receiver's row do the two copies below and no span, so
+                               // that they run beside the span walk instead of in front of it
     const double *head_src;    // the output stream is double-buffered: the last head_hist elements of the previous block (head_n of them,
     int head_hist, head_n;     // in the twin head_src) go in front of this block's first output (null: a k_save_tails launch does it)
 };
@@ -430,8 +432,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FE_WAVES_PER
     constexpr int NIT = FW_CHUNK / 64;
     const int mix = a.mt.mix_on[rx];
     // the next block's history (its own buffer: nobody reads it in this launch), a sample or two per lane across the grid
-    if (a.hist_out) mixhist_update(a, a.hist_out, a.v0_next, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
-    if (a.head_src) front_head_copy(a, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
+    if (a.helpers > 0) {
+        const int hb = (int)blockIdx.x - ((int)gridDim.x - a.helpers);
+        if (hb >= 0) {
+            if (a.hist_out) mixhist_update(a, a.hist_out, a.v0_next, rx, hb * 64 + lane, a.helpers * 64);
+            if (a.head_src) front_head_copy(a, rx, hb * 64 + lane, a.helpers * 64);
+            return;
+        }
+    } else {
+        if (a.hist_out) mixhist_update(a, a.hist_out, a.v0_next, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
+        if (a.head_src) front_head_copy(a, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
+    }
     const double2 *histp = a.hist + (long long)rx * a.H;
     double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
     const long long dummy = (long long)a.out.plane_stride - a.out.hist - 1;     // last slot of the plane: never a sample
@@ -448,7 +459,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FE_WAVES_PER
         }
     }
 #endif
-  for (int span = blockIdx.x; span < a.nspans; span += gridDim.x) {
+  for (int span = blockIdx.x; span < a.nspans; span += gridDim.x - a.helpers) {
     const long long g_lo = a.g_lo0 + (long long)span * a.span_len;
     if (g_lo >= a.g_end) break;
     const long long g_hi = (g_lo + a.span_len < a.g_end) ? g_lo + a.span_len : a.g_end;
@@ -703,8 +714,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WAVES_PER
     constexpr int NIT = PK_CHUNK / 64;
     const int mix = a.mt.mix_on[rx];
     // the next block's history (its own buffer: nobody reads it in this launch), a sample or two per lane across the grid
-    if (a.hist_out) mixhist_update(a, a.hist_out, a.v0_next, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
-    if (a.head_src) front_head_copy(a, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
+    if (a.helpers > 0) {
+        const int hb = (int)blockIdx.x - ((int)gridDim.x - a.helpers);
+        if (hb >= 0) {
+            if (a.hist_out) mixhist_update(a, a.hist_out, a.v0_next, rx, hb * 64 + lane, a.helpers * 64);
+            if (a.head_src) front_head_copy(a, rx, hb * 64 + lane, a.helpers * 64);
+            return;
+        }
+    } else {
+        if (a.hist_out) mixhist_update(a, a.hist_out, a.v0_next, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
+        if (a.head_src) front_head_copy(a, rx, blockIdx.x * 64 + lane, gridDim.x * 64);
+    }
     const double2 *histp = a.hist + (long long)rx * a.H;
     double *out0 = sv_ptr(a.out, rx, 0), *out1 = sv_ptr(a.out, rx, 1);
     float *outf0 = sv_ptr_t<float>(a.out, rx, 0), *outf1 = sv_ptr_t<float>(a.out, rx, 1);
@@ -716,7 +736,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WAVES_PER
     // p^(64 it) in float for the samples of a chunk, p^64 and p^768 in double for the lane's own phasor
     const double2 P64 = a.mt.tabB[rx * 64 + 1], PCH = a.mt.tabB[rx * 64 + NIT];
     const qk_f2 P64f = qk_f2{(float)P64.x, (float)P64.y};
-  for (int span = blockIdx.x; span < a.nspans; span += gridDim.x) {
+  for (int span = blockIdx.x; span < a.nspans; span += gridDim.x - a.helpers) {
     const long long g_lo = a.g_lo0 + (long long)span * a.span_len;
     if (g_lo >= a.g_end) break;
     const long long g_hi = (g_lo + a.span_len < a.g_end) ? g_lo + a.span_len : a.g_end;
@@ -1963,13 +1983,16 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
                 if (++spins > AGC_SPIN_LIMIT || uni(peek(&aborted))) { poke(&aborted, 1); alive = false; }
             }
             double tm = 0.0;                        // lane u: the maximum over tile u
+            const int nt = T - ch * AGC_CHUNK;      // tiles of this chunk that exist (a short block has a handful)
 #pragma unroll
             for (int u = 0; u < AGC_CHUNK; ++u) {
-                double m = fabs(v[u]);
-                sm[ch & 1][u * 64 + lane] = m;
+                if (u < nt) {
+                    double m = fabs(v[u]);
+                    sm[ch & 1][u * 64 + lane] = m;
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(m, off); m = o > m ? o : m; }
-                if (lane == u) tm = m;
+                    for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_xor(m, off); m = o > m ? o : m; }
+                    if (lane == u) tm = m;
+                }
             }
             if (lane < AGC_CHUNK) tmaxs[ch & 1][lane] = tm;
             AGC_LDS_WAIT();
