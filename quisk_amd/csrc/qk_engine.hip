@@ -2496,12 +2496,12 @@ int qk_create(qk_engine **out, const qk_config *cfg)
     const int pr = cfg->playback_rate / 48000;
     if (cfg->playback_rate % 48000 || (pr != 1 && pr != 2 && pr != 4 && pr != 8))
         return fail(QK_EINVAL, "playback_rate must be 48000 x {1,2,4,8} (quisk.c:2535-2553)");
-    int ndev = 0;
+    if (cfg->reserved[1] != 0 && cfg->reserved[1] != 1) return fail(QK_EINVAL, "qk_config.reserved[1]: 0 = fp64, 1 = fp32 mode");
+    if (cfg->reserved[2] < 0 || cfg->reserved[2] > 2) return fail(QK_EINVAL, "qk_config.reserved[2]: short-block mode 0 = by max_block, 1 = on, 2 = off");
+    int ndev = 0;       // (the arguments are judged before the device is: the CPU tests reach every message above)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(QK_EHIP, "no HIP device: the engine has no CPU path");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(QK_EINVAL, "bad device ordinal");
-    if (cfg->reserved[1] != 0 && cfg->reserved[1] != 1) return fail(QK_EINVAL, "qk_config.reserved[1]: 0 = fp64, 1 = fp32 mode");
-    if (cfg->reserved[2] < 0 || cfg->reserved[2] > 2) return fail(QK_EINVAL, "qk_config.reserved[2]: short-block mode 0 = by max_block, 1 = on, 2 = off");
     qk_engine *e = new (std::nothrow) qk_engine();
     if (!e) return fail(QK_ENOMEM, "out of host memory");
     e->cfg = *cfg;

@@ -64,3 +64,32 @@ def test_engine_fails_loudly_without_a_gpu():
         return
     eng.close()
     pytest.skip("a GPU is present")
+
+
+def test_qk_create_judges_its_arguments_before_the_device():
+    """qk_create refuses a bad configuration with QK_EINVAL and its own message whether or not a GPU is there (the argument
+    checks come first): sample rate, playback rate (quisk.c:2535-2553), the fp32 selector, the short-block selector."""
+    from quisk_amd.engine import lib, QkConfig
+    L = lib()
+    L.qk_last_error.restype = ctypes.c_char_p
+
+    def create(**kw):
+        base = dict(device=0, sample_rate=192000, playback_rate=48000, n_receivers=1, max_block=960, fft_size=0, data_width=0)
+        res = kw.pop("reserved", {})
+        base.update(kw)
+        cfg = QkConfig(**base)
+        for k, v in res.items():
+            cfg.reserved[k] = v
+        h = ctypes.c_void_p()
+        rc = L.qk_create(ctypes.byref(h), ctypes.byref(cfg))
+        msg = (L.qk_last_error() or b"").decode()
+        if rc == 0:
+            L.qk_destroy(h)
+        return rc, msg
+
+    QK_EINVAL = -1
+    for kw, needle in ((dict(sample_rate=8000), "sample_rate"), (dict(playback_rate=44100), "playback_rate"),
+                       (dict(max_block=0), "max_block"), (dict(reserved={1: 2}), "reserved[1]"), (dict(reserved={2: 3}), "reserved[2]"),
+                       (dict(reserved={2: -1}), "reserved[2]")):
+        rc, msg = create(**kw)
+        assert rc == QK_EINVAL and needle in msg, (kw, rc, msg)
