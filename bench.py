@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-config5", action="store_true", help="skip the configs[4] fp32 slice leg")
     ap.add_argument("--no-one-gpu", action="store_true", help="skip the 1024-receivers-on-one-GPU leg")
     ap.add_argument("--cpu-samples", type=int, default=1 << 21)
+    ap.add_argument("--preroll-ms", type=float, default=30.0, help="run the leg's blocks untimed for this long before the W warm-up steps (clock conditioning)")
     return ap.parse_args()
 
 
@@ -199,9 +200,23 @@ def make_engine(fs, nrx, block, local, tunes, modes, fp32=False, **kw):
     return eng
 
 
-def timed_leg(eng, ptrs, block, steps, warmup, barrier, timing_groups):
+PREROLL_MS = 30.0
+
+
+def timed_leg(eng, ptrs, block, steps, warmup, barrier, timing_groups, preroll_ms=None):
     """W untimed steps, then exactly K steps between barriers; returns (seconds, stats)."""
     nb = len(ptrs)
+    if preroll_ms is None:
+        preroll_ms = PREROLL_MS
+    if preroll_ms > 0:
+        # clock conditioning, not part of the measurement: the same blocks for PREROLL_MS of wall time, so that the W + K steps
+        # below run at the clocks of a stream that has been running (the GPU's clocks take ~20 ms of load to come up from idle)
+        t_end = time.perf_counter() + preroll_ms * 1e-3
+        i = 0
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                eng.process_device(ptrs[i % nb], block); i += 1
+            eng.sync()
     for i in range(warmup):
         eng.process_device(ptrs[i % nb], block)
     eng.sync()
@@ -386,6 +401,8 @@ def config1_leg(local, with_cpu):
 
 def main():
     a = parse()
+    global PREROLL_MS
+    PREROLL_MS = a.preroll_ms
     if a.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
@@ -456,9 +473,9 @@ def main():
 
     # The headline leg runs twice: once straight after set-up, when the GPU has been idle (its clocks take some 20 ms of
     # load to come up: a 20-step timed region lies wholly inside that ramp), and again -- the figure reported as `value` --
-    # after the C4 / C5 legs have kept the GPU busy, i.e. at the clocks a receiver that runs for more than a few
+    # behind a pre-roll of its own blocks (PREROLL_MS, untimed), i.e. at the clocks a receiver that runs for more than a few
     # milliseconds sees.  Both are W warm-up steps followed by exactly K timed steps between barriers.
-    dt_idle, _ = timed_leg(eng, ptrs, block, a.steps, a.warmup, barrier, (KT_FRONTEND,))
+    dt_idle, _ = timed_leg(eng, ptrs, block, a.steps, a.warmup, barrier, (KT_FRONTEND,), preroll_ms=0.0)
     dt_idle = max_over_ranks(dt_idle, torch.device("cuda", local))
     res = {}
     later = []
@@ -547,7 +564,11 @@ def main():
         "roofline": frontend_roofline(st, fs, block, nrx, step_ms, a.fp32, "r03_pmc_frontend_c2.json", "r03_kernel_stats_default_bench.csv"),
     }
     res["after_idle"] = {"ms_per_step": dt_idle / a.steps * 1e3, "value": a.steps * block * world / dt_idle / 1e6,
-                         "note": "the same leg run first, straight after set-up: the GPU's clocks are still coming up from idle"}
+                         "note": "the same leg run first, straight after set-up and without the pre-roll: the GPU's clocks are still coming up from idle"}
+    res["preroll_ms"] = PREROLL_MS
+    res["preroll_note"] = ("clock conditioning outside the measurement: every leg runs its own blocks untimed for this long in front of its W warm-up "
+                           "steps (the GPU's clocks need ~20 ms of load to come up from idle; a receiver runs for hours); the timed region is "
+                           "still exactly K steps between barriers; `after_idle` is the figure without it")
     res.update(res0)
     if gather is not None:
         res["gather"] = gather
