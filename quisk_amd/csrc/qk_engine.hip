@@ -159,6 +159,9 @@ struct qk_engine {
     hipEvent_t ev_read[2] = {nullptr, nullptr};        // the chains have finished reading front-stream twin q
     bool read_pending[2] = {false, false};
     int fe_blocks = 0;                                 // blocks in which the front end produced output (twin parity)
+    // QK_TIMELINE=<file>: eight stream marks per block over a window of blocks, written out as csv when the engine goes (a
+    // measuring aid: where a block's stages sit in time against each other; profiles/tools/stream_marks.py reads it)
+    std::vector<hipEvent_t> tl_ev; int tl_first = 0, tl_n = 0; std::string tl_path;
     long long pipe_blocks = 0;                         // blocks run by the receivers' pipeline: selects every ping-pong set (events, gains,
                                                        // squelch flags).  Not stats.blocks, which qk_reset_stats zeroes between blocks.
     bool agc_pending = false;
@@ -1069,6 +1072,12 @@ static int engine_init(qk_engine *e)
     HIPCHECK(hipSetDevice(cfg.device));
     e->small_mode = cfg.reserved[2] == 1 || (cfg.reserved[2] == 0 && cfg.max_block <= 4096);
     if (const char *v = getenv("QK_SMALL_MODE")) e->small_mode = atoi(v) != 0;
+    if (const char *v = getenv("QK_TIMELINE")) {
+        const char *w = getenv("QK_TIMELINE_FIRST"), *c = getenv("QK_TIMELINE_BLOCKS");
+        e->tl_path = v; e->tl_first = w ? atoi(w) : 60; e->tl_n = std::min(256, std::max(1, c ? atoi(c) : 48));
+        e->tl_ev.resize((size_t)e->tl_n * 8);
+        for (auto &ev : e->tl_ev) HIPCHECK(hipEventCreate(&ev));
+    }
     HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     if (e->small_mode) {
         // one stream under four names: the events between the stages become same-stream no-ops
@@ -1203,6 +1212,33 @@ struct Timer {      // bucket 0..7 = QK_KT_*, 8 = whole block
         e->ev_pending.push_back({bucket, e0, e0 + 1});
     }
 };
+inline void tl_mark(qk_engine *e, int point, hipStream_t st)
+{
+    if (e->tl_ev.empty()) return;
+    const long long b = e->pipe_blocks - e->tl_first;
+    if (b < 0 || b >= e->tl_n) return;
+    hipEventRecord(e->tl_ev[(size_t)b * 8 + point], st);
+}
+void tl_dump(qk_engine *e)
+{
+    if (e->tl_ev.empty()) return;
+    FILE *f = fopen(e->tl_path.c_str(), "w");
+    if (f) {
+        fprintf(f, "block,fe_start,fe_end,chain_start,chain_end,agc_start,gain_end,agc_end,block_end\n");
+        for (int b = 0; b < e->tl_n && e->tl_first + b < e->pipe_blocks; b++) {
+            fprintf(f, "%d", e->tl_first + b);
+            for (int k = 0; k < 8; k++) {
+                float ms = -1;
+                if (hipEventElapsedTime(&ms, e->tl_ev[0], e->tl_ev[(size_t)b * 8 + k]) != hipSuccess) ms = -1;
+                fprintf(f, ",%.4f", ms);
+            }
+            fprintf(f, "\n");
+        }
+        fclose(f);
+    }
+    for (auto ev : e->tl_ev) hipEventDestroy(ev);
+    e->tl_ev.clear();
+}
 }  // namespace
 
 static inline dim3 grid1(int n, int planes, int nz) { return dim3((unsigned)((n + 255) / 256), (unsigned)planes, (unsigned)nz); }
@@ -1692,6 +1728,14 @@ static int measure_freq_block(qk_engine *e, const Stream &dec)
     return QK_OK;
 }
 
+// QK_DEBUG_SKIP (a measuring aid beside QK_TIMELINE; the audio is wrong with it), bits: 1 = no AGC launches, 2 = no chain
+// launches at all, 4 = no FIR decimator launches, 8 = no receive-filter launches, 16 = no interpolator launches
+static int debug_skip()
+{
+    static const int v = [] { const char *t = getenv("QK_DEBUG_SKIP"); return t ? atoi(t) : 0; }();
+    return v;
+}
+
 // run one chain over `nlist` receivers; `input` is the stream feeding stage.in == -1
 // May this run of a chain go out as one launch (k_chain_fused)?  Short blocks only (one workgroup per receiver does all the
 // work), chains made of the stage kinds the kernel knows, and none of the audio hooks that are kernels of their own.
@@ -1743,7 +1787,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
                 FStage &f = fz_add(FS_FIR, in_v, out_v, in.planes, n_in, n_out);
                 f.h = (e->fp32 && st.hf) ? (const void *)st.hf : (const void *)st.h; f.sub = (e->fp32 && st.hf) ? 1 : 0;
                 f.D = st.D; f.TQP = st.TQP; f.first = first;
-            } else if (n_out > 0) {
+            } else if (n_out > 0 && !(debug_skip() & 4)) {
                 const bool f32 = e->fp32 && st.hf;
                 FirTArgs a{in_v, out_v, f32 ? (const void *)st.hf : (const void *)st.h, st.TQP, first, n_out, d_list, in.f32 ? 1 : 0, out.f32 ? 1 : 0};
                 Timer tm(e, st.timer, cs);
@@ -1772,7 +1816,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             if (out.n > 0 && fuse) {
                 FStage &f = fz_add(FS_INTERP, in.view(), out.view(), 1, n_in, out.n);
                 f.h = st.h; f.T = st.T; f.L = st.L; f.delay = 0;
-            } else if (out.n > 0) {
+            } else if (out.n > 0 && !(debug_skip() & 16)) {
                 InterpArgs a{in.view(), out.view(), st.h, st.T, st.L, n_in, d_list, (st.delayed && e->ssb_sq_enabled) ? SSQ_N : 0};
                 Timer tm(e, st.timer, cs);
                 hipLaunchKernelGGL(k_interp, grid1(out.n, 1, nlist), dim3(256), 0, cs, a);
@@ -1783,7 +1827,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             out.n = n_in * 2;
             if (n_in > 0 && fuse) {
                 fz_add(FS_HBINT, in.view(), out.view(), in.planes, n_in, out.n).delay = 0;
-            } else if (n_in > 0) {
+            } else if (n_in > 0 && !(debug_skip() & 16)) {
                 HbInterpArgs a{in.view(), out.view(), n_in, d_list, (st.delayed && e->ssb_sq_enabled) ? SSQ_N : 0};
                 Timer tm(e, st.timer, cs);
                 hipLaunchKernelGGL(k_hb_interp, grid1(n_in, in.planes, nlist), dim3(256), 0, cs, a);
@@ -1808,7 +1852,7 @@ static int run_chain(qk_engine *e, Chain &c, const Stream &input, const int *d_l
             st.total_in += n_in;
             if (n_in > 0 && fuse) {
                 fz_add(FS_RXF, in.view(), out.view(), 2, n_in, n_in).sub = st.rxf_kind;
-            } else if (n_in > 0) {
+            } else if (n_in > 0 && !(debug_skip() & 8)) {
                 // measure_audio's sum rides in the kernel's epilogue where this stage is the one it measures
                 const bool ma_here = st.measure_div > 0 && d_list && !c.members.empty() && c.members[0] == 0;
                 RxfArgs a{in.view(), out.view(), e->fp32 ? (const void *)e->d_taps_f : (const void *)e->d_taps, e->d_ntaps, e->d_mode, e->tap_cap, n_in,
@@ -2151,6 +2195,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     }
     fa.out = F.streams[0].view();
     fa.out_f32 = F.streams[0].f32 ? 1 : 0;
+    tl_mark(e, 0, e->fe_stream);
     {
         Timer tm(e, QK_KT_FRONTEND, e->fe_stream);
         if (S == 0) {
@@ -2163,6 +2208,8 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             long long want = std::max(1LL, target_wgs / std::max(1, e->nrx));
             long long span = (consumed + want - 1) / want;
             span = std::max(span, 4 * unit);
+            static const int span_env = [] { const char *v = getenv("QK_FE_SPAN"); return v ? atoi(v) : 0; }();      // (experiments)
+            if (span_env > 0) span = span_env;
             span = (span + unit - 1) / unit * unit;
             const int nspans = (int)((consumed + span - 1) / span);
             fa.span_len = (int)span; fa.nspans = nspans;
@@ -2200,7 +2247,9 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     {
         hipEvent_t evf = (e->pipe_blocks & 1) ? e->ev_fe2 : e->ev_fe;
         if (!e->small_mode) HIPCHECK(hipEventRecord(evf, e->fe_stream));     // (short blocks: one stream, the order is the stream's own)
+        tl_mark(e, 1, e->fe_stream);
         HIPCHECK(hipStreamWaitEvent(e->stream, evf, 0));
+        tl_mark(e, 2, e->stream);
     }
     // ---- remaining integer decimation, all receivers ----
     // short blocks, one class with every receiver in order, nothing between the front chain and it: one fused launch for both
@@ -2214,7 +2263,8 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             e->fz_defer = ident;
         }
     }
-    int rc = run_chain(e, F, F.streams[0], nullptr, e->nrx, e->stream);
+    const int dbg_skip = debug_skip();
+    int rc = (dbg_skip & 2) ? QK_OK : run_chain(e, F, F.streams[0], nullptr, e->nrx, e->stream);
     if (rc != QK_OK) return rc;
     const Stream &dec = F.streams[F.aud];
     if (e->mf_mode > 0 && dec.n > 0) { rc = measure_freq_block(e, dec); if (rc != QK_OK) return rc; }      // quisk.c:2400-2401
@@ -2250,7 +2300,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         // the play-rate stream is double-buffered: this block writes the twin whose history the previous block's
         // tail copy prepared, while the AGC pass of the previous block may still read the other one
         std::swap(c.streams[c.play].d, c.play_alt);
-        rc = run_chain(e, c, dec, c.d_members, nl, lanes[lane_of[cl]]);
+        rc = (dbg_skip & 2) ? QK_OK : run_chain(e, c, dec, c.d_members, nl, lanes[lane_of[cl]]);
         if (rc != QK_OK) return rc;
         c.n_out = c.streams[c.play].n;
         if (c.n_out == 0) std::swap(c.streams[c.play].d, c.play_alt);     // nothing written: stay on the same twin
@@ -2292,7 +2342,9 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         e->out_count[r.rx] = t.n_out;
     }
     if (!e->small_mode) HIPCHECK(hipEventRecord(e->ev_chain, e->stream));
+    tl_mark(e, 3, e->stream);
     HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_chain, 0));
+    tl_mark(e, 4, e->agc_stream);
     if (fe_writes) {
         if (!e->small_mode) HIPCHECK(hipEventRecord(e->ev_read[q], e->stream));
         e->read_pending[q] = true;
@@ -2316,7 +2368,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             m_max = std::max(m_max, a.n_c[cl]);
         }
         e->last_m_max = m_max;
-        if (m_max > 0) {
+        if (m_max > 0 && !(dbg_skip & 1)) {
             a.cls = e->d_agc_cls; a.gains = (e->apply_stream && par) ? e->d_gains2 : e->d_gains; a.gain_stride = e->gain_stride;
             a.buf_size = rate * 15 / 1000; a.n_rx = e->nrx;
             a.ceiling = 0.7 * QK_CLIP32;                                         // Agc1 max_out, quisk.c:2181
@@ -2337,6 +2389,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
             static const bool ext_launch = [] { const char *v = getenv("QK_AGC_EXT_LAUNCH"); return !v || atoi(v) != 0; }();
             if (own && ext_launch) hipExtLaunchKernelGGL(k_agc_gain, dim3(e->nrx), dim3(192), 0, e->agc_stream, nullptr, e->ev_gain, 0, a);
             else hipLaunchKernelGGL(k_agc_gain, dim3(e->nrx), dim3(192), 0, e->agc_stream, a);
+            tl_mark(e, 5, e->agc_stream);
             hipStream_t aps = e->agc_stream;
             if (!own && e->last_apply_own && e->agc_pending)
                 HIPCHECK(hipStreamWaitEvent(e->agc_stream, e->ev_agc[par ^ 1], 0));      // the previous apply pass, on the other stream
@@ -2398,6 +2451,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         int rco = output_stage(e, agc_ev_stream);
         if (rco != QK_OK) return rco;
     }
+    tl_mark(e, 6, agc_ev_stream);
     if (!e->small_mode) HIPCHECK(hipEventRecord(e->ev_agc[par], agc_ev_stream));
     else { HIPCHECK(hipEventRecord(e->ev_audio, e->stream)); e->audio_ev = true; }
     // ---- carry stream tails ----
@@ -2470,6 +2524,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
         e->agc_pending = true;
     }
     if (e->fftN > 0 && spectrum_last) { int rcs = feed_spectrum(e, x, n); if (rcs != QK_OK) return rcs; }
+    tl_mark(e, 7, e->stream);
     HIPCHECK(hipGetLastError());
     e->stats.samples_in += n;
     e->stats.blocks += 1;
@@ -2521,6 +2576,7 @@ void qk_destroy(qk_engine *e)
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->agc_stream) hipStreamSynchronize(e->agc_stream);
     if (e->apply_stream) hipStreamSynchronize(e->apply_stream);
+    tl_dump(e);
     free_chain(e->front);
     for (auto &c : e->cls_chain) free_chain(c);
     blue_free(e->blue);

@@ -427,6 +427,9 @@ template <int S, class T = double>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FE_WAVES_PER_EU, FE_WAVES_PER_EU))) void k_frontend_wave(FrontArgs a)
 {
     __shared__ __attribute__((aligned(16))) T smem[FwLayout::total(S)];
+#ifdef FE_PRIO       // (experiment, profiles/ub/README.md "wave priority": the front end's launch shortens, the block period does not)
+    __builtin_amdgcn_s_setprio(FE_PRIO);
+#endif
     const int rx = blockIdx.y, lane = threadIdx.x;
     constexpr int W = FwLayout::warm(S);
     constexpr int NIT = FW_CHUNK / 64;
