@@ -712,6 +712,9 @@ template <int S>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WAVES_PER_EU, PK_WAVES_PER_EU))) void k_frontend_pk(FrontArgs a)
 {
     __shared__ __attribute__((aligned(16))) qk_f2 smem[PkLayout::total(S)];
+#ifdef FE_PRIO
+    __builtin_amdgcn_s_setprio(FE_PRIO);
+#endif
     const int rx = blockIdx.y, lane = threadIdx.x;
     constexpr int W = FwLayout::warm(S);
     constexpr int NIT = PK_CHUNK / 64;

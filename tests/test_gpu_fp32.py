@@ -92,6 +92,37 @@ def test_fp32_audio_config5_slice_dynamic_range():
     assert max(pre) <= 1e-5
 
 
+def test_fp32_config5_slice_at_bench_geometry():
+    """The per-GPU share of configs[4] as bench.py's config5_slice leg runs it: 128 mixed receivers at 61.44 Msps in fp32 mode,
+    blocks of 2^20 samples, the 2^20-point display FFT of every block beside them (the packed float front end's span partition
+    depends on receiver count and block length both).  Audio to the stated tolerance, AGC bit-exact, the averaged row <= 0.01 dB."""
+    fs, nrx, N, W = 61440000, 128, 1 << 20, 4096
+    tunes, modes = tune_offsets(nrx, fs), mode_mix(nrx, "mixed")
+    sizes = [N, N, N]
+    x = make_iq(sum(sizes), fs, tunes, modes, 1006)       # a carrier for every receiver: an FM discriminator on noise alone amplifies any input difference
+    eng = Engine(fs, n_receivers=nrx, max_block=N, fft_size=N, data_width=W, fp32=True)
+    pr = PairRunner(eng, modes, tunes)
+    og = B.OracleGraph(N, W, fs)
+    _, _, bw0, off0 = rx_filter(fs, int(modes[0]))
+    og.set_passband(int(tunes[0]), off0, bw0)           # the S-meter reads receiver 0's passband
+    pos = 0
+    for n in sizes:
+        pr.step(x[pos:pos + n])
+        pos += n
+    og.add_frames(x)
+    n_got, row, sm = eng.get_graph(1.0, 0.0)
+    n_want, want, want_sm = og.release(1.0, 0.0)
+    pr.close(); og.close()
+    assert pr.agc_exact and len(pr.log) == nrx
+    floor = 1e-3 * float(np.max(np.abs(x)))
+    pre = [_rms_rel(lg["pg"], lg["po"], floor) for lg in pr.log]
+    err = np.abs(row - want)
+    print("fp32, 128 receivers + 2^20-point FFT: worst pre-AGC RMS error %.1e (median %.1e); row %.2e dB, S-meter %.2e dB"
+          % (max(pre), float(np.median(pre)), err.max(), abs(sm - want_sm)))
+    assert max(pre) <= 1e-5 and max(pre) > 1e-9
+    assert n_got == n_want == len(sizes) and err.max() <= 0.01 and abs(sm - want_sm) <= 0.01
+
+
 @pytest.mark.parametrize("N,W,frames", [(4096 * 4, 1024, 3), (1 << 20, 4096, 8)])
 def test_fp32_spectrum(N, W, frames):
     fs = 61440000
