@@ -2457,7 +2457,7 @@ static int process_device(qk_engine *e, const double2 *x, int n)
     // ---- carry stream tails ----
     {
         // (short blocks: the front chain's and the classes' tails leave in ONE launch, each entry with its own receiver list)
-        const bool merge = e->small_mode;
+        const bool merge = e->small_mode;      // (in the pipelined mode one merged launch measured no shorter: 0.3227 against 0.3217 ms at config 2)
         TailArgs all{}; all.count = 0; all.rx_list = nullptr;
         TailArgs ta{}; ta.count = 0; ta.rx_list = nullptr;
         if (merge) add_tails(all, F, 0, nullptr, e->nrx);
