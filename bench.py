@@ -430,8 +430,6 @@ def main():
     lo, hi = receiver_slice(total_rx, world, rank)
     tunes, modes = all_tunes[lo:hi], all_modes[lo:hi]
     eng = make_engine(fs, nrx, block, local, tunes, modes, fp32=a.fp32)
-    if world > 1:
-        init_comm(eng)
 
     # synthetic stream resident in HBM: NB distinct blocks (the base block rotated by a different phase each),
     # 256 MiB in total so that successive steps do not re-read a cache-resident input
@@ -470,6 +468,9 @@ def main():
         if rank == 0:
             assert int(cnt.min().item()) > 0 and bool(torch.isfinite(dst[:, :, :int(cnt.min().item())]).all().item())
         return {"ms": ms, "bytes": int(n_local * world * stride * 16), "receivers": n_local * world, "backend": "rccl-c"}
+
+    if world > 1:
+        init_comm(eng)
 
     # The headline leg runs twice: once straight after set-up, when the GPU has been idle (its clocks take some 20 ms of
     # load to come up: a 20-step timed region lies wholly inside that ramp), and again -- the figure reported as `value` --
