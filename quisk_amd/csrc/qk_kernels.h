@@ -427,9 +427,6 @@ template <int S, class T = double>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FE_WAVES_PER_EU, FE_WAVES_PER_EU))) void k_frontend_wave(FrontArgs a)
 {
     __shared__ __attribute__((aligned(16))) T smem[FwLayout::total(S)];
-#ifdef FE_PRIO       // (experiment, profiles/ub/README.md "wave priority": the front end's launch shortens, the block period does not)
-    __builtin_amdgcn_s_setprio(FE_PRIO);
-#endif
     const int rx = blockIdx.y, lane = threadIdx.x;
     constexpr int W = FwLayout::warm(S);
     constexpr int NIT = FW_CHUNK / 64;
@@ -451,7 +448,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FE_WAVES_PER
     const long long dummy = (long long)a.out.plane_stride - a.out.hist - 1;     // last slot of the plane: never a sample
 #if FE_PRIO
     {   // The two waves that share a SIMD get different issue priorities (from their wave slot), so that one of them
-        // fills the other's LDS waits instead of both marching in step from read block to FMA block.
+        // fills the other's LDS waits instead of both marching in step from read block to FMA block.  (-DFE_PRIO=1, an
+        // experiment: three waves in four then also stand above the chain kernels' priority 0 -- round 3: the launch shortens
+        // from 0.307 to 0.276 ms at config 2 and the block period stays, profiles/ub/README.md "block period")
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         switch (hwid & 3u) {
@@ -712,9 +711,6 @@ template <int S>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WAVES_PER_EU, PK_WAVES_PER_EU))) void k_frontend_pk(FrontArgs a)
 {
     __shared__ __attribute__((aligned(16))) qk_f2 smem[PkLayout::total(S)];
-#ifdef FE_PRIO
-    __builtin_amdgcn_s_setprio(FE_PRIO);
-#endif
     const int rx = blockIdx.y, lane = threadIdx.x;
     constexpr int W = FwLayout::warm(S);
     constexpr int NIT = PK_CHUNK / 64;
