@@ -446,17 +446,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    comm_bad, comm_err = set(), []
+
     def init_comm(e):
         """the library's own RCCL communicator (qk_comm_init): rank 0 makes the id, the launcher's process group only carries it"""
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(e.comm_unique_id()), dtype=torch.uint8))
+            try:
+                uid.copy_(torch.frombuffer(bytearray(e.comm_unique_id()), dtype=torch.uint8))
+            except Exception as ex:      # (an all-zero id tells the other ranks)
+                comm_err.append(str(ex))
         dist.broadcast(uid, 0)
-        e.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        ok = torch.ones(1, dtype=torch.int32, device="cuda")
+        try:
+            if not bool(uid.any().item()):
+                raise RuntimeError("no unique id from rank 0")
+            e.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+        except Exception as ex:          # the gather is reported, not measured as `value`: a rank without a communicator
+            ok.zero_()                   # must not cost the run its headline -- every rank then leaves the gather out
+            comm_err.append(str(ex))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            comm_bad.add(id(e))
 
     def gather_outputs(e, n_local):
         """The only collective of the path: the last block's audio of every receiver to rank 0, over RCCL from inside libqkengine
         (qk_gather_audio: ncclSend / ncclRecv in one group, straight out of the engine's audio rows)."""
+        if id(e) in comm_bad:
+            return {"backend": "rccl-c", "error": "qk_comm_init failed on a rank: " + (comm_err[0] if comm_err else "see the other ranks")}
         _, stride = e.audio_device()
         dst = torch.empty((world, n_local, stride, 2), dtype=torch.float64, device="cuda") if rank == 0 else None
         cnt = torch.zeros((world, n_local), dtype=torch.int32, device="cuda") if rank == 0 else None
