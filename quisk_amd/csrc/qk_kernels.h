@@ -1443,7 +1443,9 @@ struct __attribute__((aligned(1024))) AgcRingSlot { double gv[64]; AgcSlot rec; 
 // the state (NaN gain) rather than hang the GPU.  Control flow is kept flat on purpose (one loop, one chain of
 // ifs, no early exits): a taken branch costs this single wave some twenty cycles, and the compiler's loop-exit
 // unification turns `continue` / `return` into many of them.
+#ifndef AGC_RING
 #define AGC_RING 16
+#endif
 #ifndef AGC_CHUNK
 #define AGC_CHUNK 32
 #endif
@@ -1516,7 +1518,7 @@ __device__ __forceinline__ void agc_tight_run(double &g0, const double keep, con
         AGC_MASKS
         "v_mov_b64 v[124:125], %[g0]\n\t" "v_mov_b64 v[128:129], %[g0]\n\t" "v_mov_b64 v[126:127], %[t]\n\t" "v_mov_b64 v[130:131], %[t]\n\t"
         "v_mov_b32 v115, %[aspare]\n\t" "v_mov_b32 v117, %[tagm1]\n\t" "v_mov_b32 v118, %[atm]\n\t" "v_mov_b32 v119, %[jm1]\n\t"
-        "v_mov_b32 v120, 0x3c00\n\t" "v_mov_b32 v121, %[aring]\n\t"
+        "v_mov_b32 v120, %[rmask]\n\t" "v_mov_b32 v121, %[aring]\n\t"
         "1:\n\t"
         AGC_TILE("v[124:125]", "v[124:127]", "124", "125", "v[128:129]")
         "s_add_u32 %[left], %[left], -1\n\t" "s_cbranch_scc0 2f\n\t"
@@ -1529,7 +1531,7 @@ __device__ __forceinline__ void agc_tight_run(double &g0, const double keep, con
         "3:\n\t"
         : [g0] "+v"(g0), [rm] "+v"(rmax), [left] "+s"(left)
         : [k] "v"(keep), [t] "v"(add), [aring] "v"(a_ring_lane), [aspare] "v"(a_spare_lane), [atm] "v"(a_tmax),
-          [tagm1] "v"(tag_j - 1), [jm1] "v"((j - 1) << 10)
+          [tagm1] "v"(tag_j - 1), [jm1] "v"((j - 1) << 10), [rmask] "i"((AGC_RING - 1) << 10)
         : "v112", "v113", "v115", "v117", "v118", "v119", "v120", "v121", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131",
           "s44", "s45", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "scc", "memory");
 }
@@ -1554,7 +1556,7 @@ __global__ __launch_bounds__(192) void k_agc_gain(AgcArgs a)
     // k % AGC_RING (one spare slot nobody reads)
     __shared__ __attribute__((aligned(16384))) AgcRingSlot ring[AGC_RING + 1];
     __shared__ double tmaxs[2][AGC_CHUNK];          // fetcher -> runner: max |x| over each tile of the chunk
-    static_assert(sizeof(AgcRingSlot) == 1024 && AGC_RING == 16 && offsetof(AgcRingSlot, rec) == 512 && offsetof(AgcSlot, end) == 0 && offsetof(AgcSlot, add) == 8 &&
+    static_assert(sizeof(AgcRingSlot) == 1024 && (AGC_RING == 16 || AGC_RING == 8) && offsetof(AgcRingSlot, rec) == 512 && offsetof(AgcSlot, end) == 0 && offsetof(AgcSlot, add) == 8 &&
                   offsetof(AgcSlot, tag) == 32, "agc_tight_run writes these offsets");
     __shared__ int wstat;                           // walker -> runner, fetcher: restart generation << 20 | tiles finished
     __shared__ int fetched;                         // fetcher -> walker: chunks in LDS
